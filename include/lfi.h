@@ -1,0 +1,170 @@
+/*
+ * lfi.h — C-ABI of the MI355X light-field interpolation hot path (liblfi_hip.so).
+ *
+ * This is the drop-in boundary for the reference's device-facing call sites: everything
+ * `Interpolator` (reference src/interpolator.cu) does through the CUDA runtime — surface allocation and upload,
+ * cudaMemcpyToSymbol of the parameter block, the four kernel launches, event timing, download — is replaced by
+ * the calls below.  Plain pointers and sizes only; no C++/torch types.  Each entry point cites the reference lines
+ * it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative LFI_E* code; lfi_last_error() returns the message
+ *    (the reference checks no CUDA return code at all: src/interpolator.cu:291-292);
+ *  - one context per GPU, used from one thread at a time; work is enqueued on the context's HIP stream and is
+ *    asynchronous unless stated otherwise;
+ *  - images, views and maps are tightly packed RGBA8 planes (row pitch = width*4 bytes) — the linear-HBM
+ *    replacement of the reference's cudaArray surfaces; image id g = col*rows + row (src/interpolator.cu:106-113);
+ *  - there is no CPU fallback: a missing GPU or code object is an error.
+ */
+#ifndef LFI_H
+#define LFI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFI_ABI_VERSION 1
+
+typedef struct lfi_ctx lfi_ctx;
+
+typedef struct lfi_int2 { int32_t x, y; } lfi_int2;
+typedef struct lfi_float2 { float x, y; } lfi_float2;
+
+/* error codes */
+enum {
+    LFI_OK = 0,
+    LFI_EINVAL = -1,    /* bad argument / call order */
+    LFI_EHIP = -2,      /* a HIP runtime call failed */
+    LFI_ENODEVICE = -3, /* no usable gfx950 device */
+    LFI_ENOMEM = -4
+};
+
+/* interpolation methods: the reference's -m strings (src/interpolator.cu:274,282; src/main.cpp:20-22) */
+enum {
+    LFI_METHOD_STD = 0,    /* "STD":    exact-fp32 ordered FMA chain, RN-even quantisation (src/kernels.cu:289-343) */
+    LFI_METHOD_TEN_WM = 1  /* "TEN_WM": fp16 matrix-core contraction, truncating quantisation (src/kernels.cu:345-462) */
+};
+
+/* lfi_params.flags */
+enum {
+    /* all-focus renders read focus map 1 (filtered) for both methods by default; with this flag TEN_WM reads the
+     * unfiltered map 0 as the reference does (src/kernels.cu:430 vs :326; SURVEY.md defect D7) */
+    LFI_FLAG_REFERENCE_MAP_QUIRK = 1u,
+    /* TEN_WM debug numerics: re-round the accumulator to fp16 after every 16-image batch, which reproduces the
+     * reference's half-accumulator WMMA model (oracle model M16) instead of one final rounding */
+    LFI_FLAG_TEN_ROUND_PER_BATCH = 2u
+};
+
+#define LFI_MAX_IMAGES 256     /* MAX_IMAGES, src/kernels.cu:60 */
+#define LFI_MAX_FOCUS_IDS 32   /* FOCUS_MAP_IDS_COUNT, src/kernels.cu:68 */
+#define LFI_REFERENCE_VIEWS 64 /* VIEW_TOTAL_COUNT, src/kernels.cu:11-13 (a runtime parameter here) */
+
+/*
+ * The reference's __constant__ parameter block (src/kernels.cu:15-17, 63-69) as one struct.  All pointers are HOST
+ * pointers; lfi_set_params copies what they point to.  The host code above this ABI computes these values
+ * (lfinterpolator_amd/csrc/host: same arithmetic as src/interpolator.cu:139-246) so every backend sees identical bytes.
+ */
+typedef struct lfi_params {
+    int32_t views;                    /* V: number of output views / rows of the weight matrix */
+    const lfi_int2 *focused_offsets;  /* [N] round(offset*focus): focusedOffsets, src/interpolator.cu:241-244 */
+    const lfi_float2 *offsets;        /* [N] offsets, src/interpolator.cu:240,245 */
+    const uint16_t *weights_fp16;     /* [V][N] IEEE binary16 bit patterns, row-major: src/interpolator.cu:211-223 */
+    const int32_t *focus_map_ids;     /* [n_focus_ids] focusMapIDs, src/interpolator.cu:203-206 (may be NULL if 0) */
+    int32_t n_focus_ids;              /* ≤ LFI_MAX_FOCUS_IDS */
+    float focus;                      /* inFocus, src/interpolator.cu:152 */
+    float range;                      /* inRange, src/interpolator.cu:153 */
+    int32_t block_radius[2];          /* constants[9..10], src/interpolator.cu:142-150 */
+    uint32_t flags;                   /* LFI_FLAG_* */
+} lfi_params;
+
+typedef struct lfi_bench_stats {
+    int32_t runs;
+    float mean_ms;   /* mean of per-launch event times — what the reference prints (src/interpolator.cu:270-295) */
+    float median_ms;
+    float min_ms;
+    float max_ms;
+    float back_to_back_ms; /* (one event pair around `runs` consecutive launches) / runs */
+} lfi_bench_stats;
+
+/* ---- lifetime --------------------------------------------------------------------------------------------- */
+
+/* Interpolator::Interpolator / init (src/interpolator.cu:36-50): bind to HIP device `device`, create the stream. */
+int lfi_create(int device, lfi_ctx **out_ctx);
+/* Interpolator::~Interpolator (src/interpolator.cu:41-44) — frees what the context owns; no device reset. */
+int lfi_destroy(lfi_ctx *ctx);
+/* message of the last failure on this context (ctx == NULL: last failure of lfi_create on this thread) */
+const char *lfi_last_error(const lfi_ctx *ctx);
+int lfi_abi_version(void);
+/* number of visible HIP devices (≥0) or a negative error */
+int lfi_device_count(void);
+
+/* ---- light-field grid: replaces loadGPUData / createSurfaceObject / loadImageToArray (src/interpolator.cu:73-137) --- */
+
+/* Declare a cols×rows grid of width×height RGBA8 images and allocate N = cols*rows input planes + 2 focus maps. */
+int lfi_set_grid(lfi_ctx *ctx, int cols, int rows, int width, int height);
+/* cudaMemcpy2DToArray of one image (src/interpolator.cu:91): copies; the caller keeps ownership.  Synchronous. */
+int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_bytes);
+/* Use caller-owned device memory ([N][H][W][4] u8, ≥ N*H*W*4 bytes) for the input planes instead of the context's
+ * own allocation — lets the caller fill it (e.g. an RCCL broadcast into a tensor it owns).  Call after lfi_set_grid. */
+int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes);
+/* device pointer / size of the input planes currently in use */
+int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes);
+/* fill the input planes on the device with the synthetic light field of SURVEY.md §8(d):
+ * byte = hash32(seed, g, y, x, c) >> 24, alpha 255 (identical to oracle lfo_fill_synthetic) */
+int lfi_fill_synthetic(lfi_ctx *ctx, uint32_t seed);
+
+/* ---- parameters: replaces loadGPUOffsets / loadGPUWeights / selectFocusMapViews / loadGPUConstants
+ *      (src/interpolator.cu:139-154, 194-246) ------------------------------------------------------------------ */
+int lfi_set_params(lfi_ctx *ctx, const lfi_params *params);
+/* caller-owned device memory for the V output planes ([V][H][W][4] u8); call after lfi_set_params */
+int lfi_attach_views(lfi_ctx *ctx, void *device_ptr, size_t bytes);
+int lfi_views_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes);
+
+/* ---- kernels ------------------------------------------------------------------------------------------------ */
+
+/* FocusMap::estimate + FocusMap::filter launches (src/interpolator.cu:261-266): fills maps 0 and 1. */
+int lfi_focus_map(lfi_ctx *ctx);
+/* One launch of Tensors::process / Standard::process (src/interpolator.cu:274-288) for views [v0, v1).
+ * all_focus != 0 selects the <true> instantiations (per-pixel focus from the focus map). */
+int lfi_render(lfi_ctx *ctx, int method, int all_focus, int v0, int v1);
+/* The reference's benchmark loop (src/interpolator.cu:270-295) with warm-up launches excluded. Synchronous. */
+int lfi_benchmark(lfi_ctx *ctx, int method, int all_focus, int v0, int v1, int warmup, int runs,
+                  lfi_bench_stats *out_stats);
+/* hipEvent pair on the context's stream (the reference's Timer, src/interpolator.cu:13-34) */
+int lfi_timer_start(lfi_ctx *ctx);
+int lfi_timer_stop(lfi_ctx *ctx, float *out_ms); /* records, synchronises, returns elapsed ms */
+int lfi_sync(lfi_ctx *ctx);
+
+/* ---- results: replaces storeResults' cudaMemcpy2DFromArray (src/interpolator.cu:309).  Synchronous. --------- */
+int lfi_download_view(lfi_ctx *ctx, int v, uint8_t *rgba, size_t pitch_bytes);
+int lfi_download_map(lfi_ctx *ctx, int k, uint8_t *rgba, size_t pitch_bytes);
+int lfi_upload_map(lfi_ctx *ctx, int k, const uint8_t *rgba, size_t pitch_bytes); /* tests: inject a focus map */
+
+/* ---- plumbing ------------------------------------------------------------------------------------------------- */
+
+/* enqueue on a caller-owned hipStream_t (NULL restores the context's own stream) */
+int lfi_set_stream(lfi_ctx *ctx, void *hip_stream);
+/* choose a kernel variant by name for a method ("auto" = default); used by the benchmark harness */
+int lfi_set_variant(lfi_ctx *ctx, int method, const char *name);
+/* comma separated variant names available for a method */
+const char *lfi_list_variants(int method);
+
+/* ---- debug / parity hooks --------------------------------------------------------------------------------------- */
+
+/* unclamped warped sample coordinates of image g for every pixel ([H][W] int2), computed on the device:
+ * focusCoords (src/kernels.cu:72-82).  Synchronous. */
+int lfi_download_coords(lfi_ctx *ctx, int g, int all_focus, int map_index, lfi_int2 *out_hw);
+/* accumulator values before quantisation ([H][W][3] float) of view v: fp32 sums for STD, the fp16-rounded value for
+ * TEN_WM.  Renders view v again into a scratch buffer.  Synchronous. */
+int lfi_download_prequant(lfi_ctx *ctx, int method, int all_focus, int v, float *out_hw3);
+/* hardware probe: C[32x32] = A[32x16] (fp16 bits) · B[16x32] (fp16 bits) with one v_mfma_f32_32x32x16_f16,
+ * row-major in/out — checks the fragment lane maps and fp16-subnormal handling with exact data */
+int lfi_debug_mfma_f16(lfi_ctx *ctx, const uint16_t *a_32x16, const uint16_t *b_16x32, float *c_32x32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFI_H */

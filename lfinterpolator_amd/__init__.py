@@ -1,0 +1,16 @@
+"""lfinterpolator_amd — MI355X (gfx950) light-field view interpolation hot path.
+
+The product is the C-ABI library ``lib/liblfi_hip.so`` (hand-written HIP kernels, ``include/lfi.h``) plus the C++ host
+code in ``csrc/host`` (``Interpolator``, ``LfLoader``, the command line).  This Python package is plumbing for tests and
+``bench.py``: a ctypes binding of the two shared libraries.  There is no CPU fallback — importing works without a GPU
+(so that the build and symbol checks can run anywhere), but creating a context raises unless a gfx950 device and the
+built library are present.
+"""
+from .abi import (LFI_METHOD_STD, LFI_METHOD_TEN_WM, LFI_FLAG_REFERENCE_MAP_QUIRK, LFI_FLAG_TEN_ROUND_PER_BATCH,
+                  Context, LfiError, load_hip_library, ABI_SYMBOLS)
+from .host import HostParams, build_params, load_host_library
+from .build import build_all
+
+__all__ = ["LFI_METHOD_STD", "LFI_METHOD_TEN_WM", "LFI_FLAG_REFERENCE_MAP_QUIRK", "LFI_FLAG_TEN_ROUND_PER_BATCH",
+           "Context", "LfiError", "load_hip_library", "ABI_SYMBOLS", "HostParams", "build_params", "load_host_library",
+           "build_all"]

@@ -1,0 +1,269 @@
+"""ctypes binding of include/lfi.h (lib/liblfi_hip.so).  Thin: every method is one C-ABI call."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import HIP_LIB
+
+LFI_METHOD_STD = 0
+LFI_METHOD_TEN_WM = 1
+LFI_FLAG_REFERENCE_MAP_QUIRK = 1
+LFI_FLAG_TEN_ROUND_PER_BATCH = 2
+METHODS = {"STD": LFI_METHOD_STD, "TEN_WM": LFI_METHOD_TEN_WM}
+
+# every symbol include/lfi.h declares
+ABI_SYMBOLS = [
+    "lfi_create", "lfi_destroy", "lfi_last_error", "lfi_abi_version", "lfi_device_count", "lfi_set_grid",
+    "lfi_upload_image", "lfi_attach_grid", "lfi_grid_device_ptr", "lfi_fill_synthetic", "lfi_set_params",
+    "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
+    "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_upload_map", "lfi_set_stream",
+    "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
+]
+
+
+class LfiError(RuntimeError):
+    pass
+
+
+class _Params(C.Structure):
+    _fields_ = [("views", C.c_int32), ("focused_offsets", C.c_void_p), ("offsets", C.c_void_p),
+                ("weights_fp16", C.c_void_p), ("focus_map_ids", C.c_void_p), ("n_focus_ids", C.c_int32),
+                ("focus", C.c_float), ("range", C.c_float), ("block_radius", C.c_int32 * 2), ("flags", C.c_uint32)]
+
+
+class BenchStats(C.Structure):
+    _fields_ = [("runs", C.c_int32), ("mean_ms", C.c_float), ("median_ms", C.c_float), ("min_ms", C.c_float),
+                ("max_ms", C.c_float), ("back_to_back_ms", C.c_float)]
+
+
+_lib = None
+
+
+def load_hip_library() -> C.CDLL:
+    """Load lib/liblfi_hip.so; a missing library is an error, never a fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(HIP_LIB):
+        raise LfiError(f"{HIP_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); lfinterpolator_amd has no CPU fallback")
+    lib = C.CDLL(HIP_LIB)
+    vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+    sig = {
+        "lfi_create": (i, [i, C.POINTER(vp)]),
+        "lfi_destroy": (i, [vp]),
+        "lfi_last_error": (C.c_char_p, [vp]),
+        "lfi_abi_version": (i, []),
+        "lfi_device_count": (i, []),
+        "lfi_set_grid": (i, [vp, i, i, i, i]),
+        "lfi_upload_image": (i, [vp, i, vp, sz]),
+        "lfi_attach_grid": (i, [vp, vp, sz]),
+        "lfi_grid_device_ptr": (i, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "lfi_fill_synthetic": (i, [vp, C.c_uint32]),
+        "lfi_set_params": (i, [vp, C.POINTER(_Params)]),
+        "lfi_attach_views": (i, [vp, vp, sz]),
+        "lfi_views_device_ptr": (i, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "lfi_focus_map": (i, [vp]),
+        "lfi_render": (i, [vp, i, i, i, i]),
+        "lfi_benchmark": (i, [vp, i, i, i, i, i, i, C.POINTER(BenchStats)]),
+        "lfi_timer_start": (i, [vp]),
+        "lfi_timer_stop": (i, [vp, C.POINTER(C.c_float)]),
+        "lfi_sync": (i, [vp]),
+        "lfi_download_view": (i, [vp, i, vp, sz]),
+        "lfi_download_map": (i, [vp, i, vp, sz]),
+        "lfi_upload_map": (i, [vp, i, vp, sz]),
+        "lfi_set_stream": (i, [vp, vp]),
+        "lfi_set_variant": (i, [vp, i, C.c_char_p]),
+        "lfi_list_variants": (C.c_char_p, [i]),
+        "lfi_download_coords": (i, [vp, i, i, i, vp]),
+        "lfi_download_prequant": (i, [vp, i, i, i, vp]),
+        "lfi_debug_mfma_f16": (i, [vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = the library does not export what lfi.h declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU context (lfi_ctx).  Mirrors the device-facing half of the reference's Interpolator."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_hip_library()
+        handle = C.c_void_p()
+        rc = self._lib.lfi_create(device, C.byref(handle))
+        if rc != 0:
+            raise LfiError(f"lfi_create failed ({rc}): {self._lib.lfi_last_error(None).decode()}")
+        self._h = handle
+        self.device = device
+        self.cols = self.rows = self.width = self.height = self.views = 0
+        self._keep = None
+
+    # -- helpers --------------------------------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise LfiError(f"lfi error {rc}: {self._lib.lfi_last_error(self._h).decode()}")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.lfi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def n_images(self) -> int:
+        return self.cols * self.rows
+
+    # -- grid -------------------------------------------------------------------------------------------------
+    def set_grid(self, cols: int, rows: int, width: int, height: int) -> None:
+        self._check(self._lib.lfi_set_grid(self._h, cols, rows, width, height))
+        self.cols, self.rows, self.width, self.height = cols, rows, width, height
+
+    def upload_image(self, g: int, rgba: np.ndarray) -> None:
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        assert rgba.shape == (self.height, self.width, 4)
+        self._check(self._lib.lfi_upload_image(self._h, g, _ptr(rgba), self.width * 4))
+
+    def upload_grid(self, lf: np.ndarray) -> None:
+        """lf: [N][H][W][4] u8 with g = col*rows + row."""
+        assert lf.shape == (self.n_images, self.height, self.width, 4)
+        for g in range(self.n_images):
+            self.upload_image(g, lf[g])
+
+    def attach_grid(self, device_ptr: int, nbytes: int) -> None:
+        self._check(self._lib.lfi_attach_grid(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def grid_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.lfi_grid_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def fill_synthetic(self, seed: int) -> None:
+        self._check(self._lib.lfi_fill_synthetic(self._h, seed))
+
+    # -- parameters --------------------------------------------------------------------------------------------
+    def set_params(self, hp, flags: int = 0) -> None:
+        """hp: lfinterpolator_amd.host.HostParams (or anything with the same arrays)."""
+        p = _Params()
+        foc = np.ascontiguousarray(hp.focused_offsets, dtype=np.int32)
+        off = np.ascontiguousarray(hp.offsets, dtype=np.float32)
+        w = np.ascontiguousarray(hp.weights, dtype=np.uint16)
+        ids = np.ascontiguousarray(hp.focus_map_ids, dtype=np.int32)
+        assert foc.shape == (self.n_images, 2) and off.shape == (self.n_images, 2) and w.shape[1] == self.n_images
+        p.views = w.shape[0]
+        p.focused_offsets = foc.ctypes.data
+        p.offsets = off.ctypes.data
+        p.weights_fp16 = w.ctypes.data
+        p.focus_map_ids = ids.ctypes.data if len(ids) else None
+        p.n_focus_ids = len(ids)
+        p.focus = float(hp.focus)
+        p.range = float(hp.range)
+        p.block_radius[0] = int(hp.block_radius[0])
+        p.block_radius[1] = int(hp.block_radius[1])
+        p.flags = flags
+        self._check(self._lib.lfi_set_params(self._h, C.byref(p)))
+        self.views = w.shape[0]
+
+    def attach_views(self, device_ptr: int, nbytes: int) -> None:
+        self._check(self._lib.lfi_attach_views(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def views_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.lfi_views_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # -- kernels -------------------------------------------------------------------------------------------------
+    def focus_map(self) -> None:
+        self._check(self._lib.lfi_focus_map(self._h))
+
+    def render(self, method, all_focus: bool = False, v0: int = 0, v1: int | None = None) -> None:
+        m = METHODS[method] if isinstance(method, str) else method
+        self._check(self._lib.lfi_render(self._h, m, int(all_focus), v0, self.views if v1 is None else v1))
+
+    def benchmark(self, method, all_focus=False, v0=0, v1=None, warmup=3, runs=20) -> BenchStats:
+        m = METHODS[method] if isinstance(method, str) else method
+        st = BenchStats()
+        self._check(self._lib.lfi_benchmark(self._h, m, int(all_focus), v0, self.views if v1 is None else v1, warmup,
+                                            runs, C.byref(st)))
+        return st
+
+    def timer_start(self) -> None:
+        self._check(self._lib.lfi_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._check(self._lib.lfi_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def sync(self) -> None:
+        self._check(self._lib.lfi_sync(self._h))
+
+    def set_stream(self, hip_stream: int | None) -> None:
+        self._check(self._lib.lfi_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def set_variant(self, method, name: str) -> None:
+        m = METHODS[method] if isinstance(method, str) else method
+        self._check(self._lib.lfi_set_variant(self._h, m, name.encode()))
+
+    def list_variants(self, method) -> list[str]:
+        m = METHODS[method] if isinstance(method, str) else method
+        return self._lib.lfi_list_variants(m).decode().split(",")
+
+    # -- results -------------------------------------------------------------------------------------------------
+    def download_view(self, v: int) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._check(self._lib.lfi_download_view(self._h, v, _ptr(out), self.width * 4))
+        return out
+
+    def download_views(self, v0: int = 0, v1: int | None = None) -> np.ndarray:
+        v1 = self.views if v1 is None else v1
+        return np.stack([self.download_view(v) for v in range(v0, v1)])
+
+    def download_map(self, k: int) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._check(self._lib.lfi_download_map(self._h, k, _ptr(out), self.width * 4))
+        return out
+
+    def upload_map(self, k: int, rgba: np.ndarray) -> None:
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        assert rgba.shape == (self.height, self.width, 4)
+        self._check(self._lib.lfi_upload_map(self._h, k, _ptr(rgba), self.width * 4))
+
+    def download_coords(self, g: int, all_focus: bool = False, map_index: int = 1) -> np.ndarray:
+        out = np.empty((self.height, self.width, 2), dtype=np.int32)
+        self._check(self._lib.lfi_download_coords(self._h, g, int(all_focus), map_index, _ptr(out)))
+        return out
+
+    def download_prequant(self, method, v: int, all_focus: bool = False) -> np.ndarray:
+        m = METHODS[method] if isinstance(method, str) else method
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._check(self._lib.lfi_download_prequant(self._h, m, int(all_focus), v, _ptr(out)))
+        return out
+
+    def debug_mfma_f16(self, a_bits: np.ndarray, b_bits: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(a_bits, dtype=np.uint16)
+        b = np.ascontiguousarray(b_bits, dtype=np.uint16)
+        assert a.shape == (32, 16) and b.shape == (16, 32)
+        c = np.empty((32, 32), dtype=np.float32)
+        self._check(self._lib.lfi_debug_mfma_f16(self._h, _ptr(a), _ptr(b), _ptr(c)))
+        return c

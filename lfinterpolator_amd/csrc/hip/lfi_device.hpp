@@ -1,0 +1,100 @@
+// lfi_device.hpp — device-side helpers shared by the gfx950 kernels: the kernel argument block that replaces the
+// reference's __constant__ symbols (reference src/kernels.cu:7-70), the warp / clamp-to-edge fetch
+// (src/kernels.cu:72-82, 119-126), the focus-map decode (src/kernels.cu:134-137) and the synthetic-LF hash.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../../include/lfi.h"
+
+namespace lfi {
+
+constexpr int WAVE = 64;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// dword-aligned wide accesses: shifted image rows start at arbitrary pixel (4-byte) alignment
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// Everything a blend / focus kernel reads besides pixels.  Passed by value as the kernel argument
+// (kernarg segment → scalar loads), where the reference uses cudaMemcpyToSymbol (src/interpolator.cu:134-136,151-153).
+struct KernelArgs
+{
+    const uint8_t *__restrict__ grid;       // [N][H][W][4]   input planes          (inputSurfaces)
+    uint8_t *__restrict__ views;            // [V][H][W][4]   output planes         (outputSurfaces)
+    uint8_t *__restrict__ maps;             // [2][H][W][4]   focus maps            (mapSurfaces)
+    const lfi_int2 *__restrict__ focused;   // [Kpad]         integer offsets       (focusedOffsets), zero padded
+    const lfi_float2 *__restrict__ offsets; // [Kpad]         float offsets         (offsets), zero padded
+    const uint16_t *__restrict__ w16;       // [Vpad][Kpad]   fp16 weights, zero padded (weights, src/interpolator.cu:211)
+    const float *__restrict__ w32;          // [Vpad][Kpad]   the same weights widened to f32 (exact)
+    const float *__restrict__ w32t;         // [Kpad][Vpad]   transposed copy for view-contiguous scalar loads
+    const int32_t *__restrict__ focus_ids;  // [n_focus_ids]                        (focusMapIDs)
+    float *__restrict__ prequant;           // optional [H][W][3] accumulators of view `prequant_view`
+    int32_t prequant_view;
+    int32_t width, height;                  // constants[0..1]
+    int32_t n_images;                       // constants[5]
+    int32_t k_pad;                          // n_images rounded up to 16
+    int32_t v_pad;                          // views rounded up to 64
+    int32_t v0, v1;                         // view range of this launch
+    int32_t n_focus_ids;
+    int32_t radius_x, radius_y;             // constants[9..10]
+    int32_t map_index;                      // which focus map an all-focus render reads
+    float focus, range;                     // inFocus, inRange
+    uint32_t flags;
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi)
+{
+    return min(max(v, lo), hi);
+}
+
+// surf2Dread<uchar4>(…, cudaBoundaryModeClamp): src/kernels.cu:119-126
+__device__ __forceinline__ uint32_t fetch_px(const uint8_t *__restrict__ grid, int width, int height, int g, int x, int y)
+{
+    x = clampi(x, 0, width - 1);
+    y = clampi(y, 0, height - 1);
+    const uint32_t *plane = reinterpret_cast<const uint32_t *>(grid) + (size_t)g * (size_t)(width * height);
+    return plane[y * width + x];
+}
+
+// loadFocusFromMap: src/kernels.cu:134-137 (explicit fma: the contraction nvcc applies)
+__device__ __forceinline__ float decode_focus(const uint8_t *__restrict__ map_plane, int width, int height, int x, int y,
+                                              float focus, float range)
+{
+    x = clampi(x, 0, width - 1);
+    y = clampi(y, 0, height - 1);
+    uint32_t m = reinterpret_cast<const uint32_t *>(map_plane)[y * width + x] & 0xffu;
+    float t = __fdiv_rn(static_cast<float>(m), 255.0f);
+    return __builtin_fmaf(t, range, focus);
+}
+
+// focusCoords(int2, int, float): src/kernels.cu:78-82 — C truncation of fma(focus, offset, coord)
+__device__ __forceinline__ int warp_float(int coord, float focus, float offset)
+{
+    return static_cast<int>(__builtin_fmaf(focus, offset, static_cast<float>(coord)));
+}
+
+// blocks b, b+8, b+16… share an XCD (and its L2); give each XCD one contiguous run of the tile sequence so that
+// tiles that share cache lines at their edges meet in one L2.  Bijective for any grid size.
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t nblocks)
+{
+    const uint32_t xcd = b & 7u, idx = b >> 3;
+    const uint32_t q = nblocks >> 3, rem = nblocks & 7u;
+    return xcd * q + min(xcd, rem) + idx;
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+} // namespace lfi

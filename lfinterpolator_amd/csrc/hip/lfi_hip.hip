@@ -1,0 +1,857 @@
+// lfi_hip.hip — the C-ABI of include/lfi.h on HIP for gfx950: context, device memory, parameter upload and kernel
+// launches.  This translation unit is the whole device-facing half of the reference's Interpolator
+// (reference src/interpolator.cu:13-154, 194-316); the arithmetic that produces the parameters stays in the host code
+// above the ABI (lfinterpolator_amd/csrc/host).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/lfi.h"
+#include "blend_std.hpp"
+#include "blend_ten.hpp"
+#include "focus_map.hpp"
+#include "lfi_device.hpp"
+
+using lfi::KernelArgs;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct TenVariant
+{
+    const char *name;
+    int pxl, mt;
+};
+// first entry = default ("auto")
+constexpr TenVariant kTenVariants[] = {
+    {"direct_p1m2", 1, 2}, {"direct_p2m2", 2, 2}, {"direct_p2m1", 2, 1}, {"direct_p4m1", 4, 1}, {"direct_p1m1", 1, 1},
+};
+struct StdVariant
+{
+    const char *name;
+    int kind; // 0 = valu, 1 = mfma
+    int pxl, mt;
+};
+constexpr StdVariant kStdVariants[] = {
+    {"mfma_p1m2", 1, 1, 2}, {"mfma_p2m2", 1, 2, 2}, {"mfma_p2m1", 1, 2, 1}, {"mfma_p4m1", 1, 4, 1}, {"valu", 0, 1, 0},
+};
+
+} // namespace
+
+struct lfi_ctx
+{
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cols = 0, rows = 0, n = 0, width = 0, height = 0;
+    uint8_t *grid = nullptr;
+    bool own_grid = false;
+    size_t grid_bytes = 0;
+    uint8_t *maps = nullptr;
+    uint8_t *views = nullptr;
+    bool own_views = false;
+    size_t views_bytes = 0;
+    // parameter block
+    bool have_params = false;
+    int views_n = 0, k_pad = 0, v_pad = 0, n_focus_ids = 0;
+    void *param_blob = nullptr; // one allocation holding all parameter arrays
+    lfi_int2 *d_focused = nullptr;
+    lfi_float2 *d_offsets = nullptr;
+    uint16_t *d_w16 = nullptr;
+    float *d_w32 = nullptr, *d_w32t = nullptr;
+    int32_t *d_ids = nullptr;
+    float focus = 0, range = 0;
+    int radius[2] = {1, 1};
+    uint32_t flags = 0;
+    float *prequant = nullptr;
+    int ten_variant = 0, std_variant = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(lfi_ctx *ctx, int code, const std::string &msg)
+{
+    if(ctx)
+        ctx->err = msg;
+    else
+        g_create_error = msg;
+    return code;
+}
+
+#define LFI_HIP(ctx, call)                                                                                            \
+    do                                                                                                                \
+    {                                                                                                                 \
+        hipError_t e_ = (call);                                                                                       \
+        if(e_ != hipSuccess)                                                                                          \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? LFI_ENOMEM : LFI_EHIP,                                       \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                                           \
+    } while(0)
+
+int bind(lfi_ctx *ctx)
+{
+    LFI_HIP(ctx, hipSetDevice(ctx->device));
+    return LFI_OK;
+}
+
+size_t plane_bytes(const lfi_ctx *c)
+{
+    return (size_t)c->width * c->height * 4;
+}
+
+KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
+{
+    KernelArgs a{};
+    a.grid = c->grid;
+    a.views = c->views;
+    a.maps = c->maps;
+    a.focused = c->d_focused;
+    a.offsets = c->d_offsets;
+    a.w16 = c->d_w16;
+    a.w32 = c->d_w32;
+    a.w32t = c->d_w32t;
+    a.focus_ids = c->d_ids;
+    a.prequant = nullptr;
+    a.prequant_view = -1;
+    a.width = c->width;
+    a.height = c->height;
+    a.n_images = c->n;
+    a.k_pad = c->k_pad;
+    a.v_pad = c->v_pad;
+    a.v0 = v0;
+    a.v1 = v1;
+    a.n_focus_ids = c->n_focus_ids;
+    a.radius_x = c->radius[0];
+    a.radius_y = c->radius[1];
+    // the reference reads map 1 in Standard::process and map 0 in Tensors::process (src/kernels.cu:326 vs :430);
+    // both read the filtered map here unless the quirk flag asks for the reference's behaviour
+    a.map_index = 1;
+    if((c->flags & LFI_FLAG_REFERENCE_MAP_QUIRK) && all_focus_method == LFI_METHOD_TEN_WM)
+        a.map_index = 0;
+    a.focus = c->focus;
+    a.range = c->range;
+    a.flags = c->flags;
+    return a;
+}
+
+dim3 pixel_grid(const lfi_ctx *c)
+{
+    return dim3((c->width + 63) / 64, (c->height + 3) / 4, 1);
+}
+
+template <int PXL, int MT>
+void launch_ten(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    const int tiles_x = (c->width + 32 * PXL - 1) / (32 * PXL);
+    const int n_tiles = tiles_x * c->height;
+    const int passes = (a.v1 - a.v0 + 32 * MT - 1) / (32 * MT);
+    const int vpw = passes >= 4 ? 4 : (passes >= 2 ? 2 : 1);
+    const int tiles_per_wg = 4 / vpw;
+    const dim3 grid((n_tiles + tiles_per_wg - 1) / tiles_per_wg), block(256);
+    const bool per_batch = (c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) != 0;
+    if constexpr(PXL == 1 && MT == 2)
+    {
+        if(per_batch)
+        {
+            if(all_focus)
+                hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, true, true>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+            else
+                hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false, true>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+            return;
+        }
+    }
+    if(all_focus)
+        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, true, false>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+    else
+        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false, false>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+}
+
+template <int PXL, int MT>
+void launch_std_mfma(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    const int tiles_x = (c->width + 32 * PXL - 1) / (32 * PXL);
+    const int n_tiles = tiles_x * c->height;
+    const int passes = (a.v1 - a.v0 + 32 * MT - 1) / (32 * MT);
+    const int vpw = passes >= 4 ? 4 : (passes >= 2 ? 2 : 1);
+    const int tiles_per_wg = 4 / vpw;
+    const dim3 grid((n_tiles + tiles_per_wg - 1) / tiles_per_wg), block(256);
+    if(all_focus)
+        hipLaunchKernelGGL((lfi::blend_std_mfma<PXL, MT, true>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+    else
+        hipLaunchKernelGGL((lfi::blend_std_mfma<PXL, MT, false>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+}
+
+int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
+{
+    const bool af = all_focus != 0;
+    if(method == LFI_METHOD_TEN_WM)
+    {
+        int variant = c->ten_variant;
+        // the per-batch rounding debug mode exists for the default variant only
+        if(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH)
+            variant = 0;
+        const TenVariant &v = kTenVariants[variant];
+        if(v.pxl == 1 && v.mt == 2)
+            launch_ten<1, 2>(c, a, af);
+        else if(v.pxl == 2 && v.mt == 2)
+            launch_ten<2, 2>(c, a, af);
+        else if(v.pxl == 2 && v.mt == 1)
+            launch_ten<2, 1>(c, a, af);
+        else if(v.pxl == 4 && v.mt == 1)
+            launch_ten<4, 1>(c, a, af);
+        else
+            launch_ten<1, 1>(c, a, af);
+    }
+    else if(method == LFI_METHOD_STD)
+    {
+        const StdVariant &v = kStdVariants[c->std_variant];
+        if(v.kind == 0)
+        {
+            if(af)
+                hipLaunchKernelGGL((lfi::blend_std_valu<true, 16>), pixel_grid(c), dim3(256), 0, c->stream, a);
+            else
+                hipLaunchKernelGGL((lfi::blend_std_valu<false, 16>), pixel_grid(c), dim3(256), 0, c->stream, a);
+        }
+        else if(v.pxl == 1 && v.mt == 2)
+            launch_std_mfma<1, 2>(c, a, af);
+        else if(v.pxl == 2 && v.mt == 2)
+            launch_std_mfma<2, 2>(c, a, af);
+        else if(v.pxl == 2 && v.mt == 1)
+            launch_std_mfma<2, 1>(c, a, af);
+        else
+            launch_std_mfma<4, 1>(c, a, af);
+    }
+    else
+        // the reference throws here (src/interpolator.cu:289-290)
+        return fail(c, LFI_EINVAL, "The specified interpolation method does not exist!");
+    LFI_HIP(c, hipGetLastError());
+    return LFI_OK;
+}
+
+int check_render_args(lfi_ctx *c, int method, int v0, int v1)
+{
+    if(!c)
+        return LFI_EINVAL;
+    if(!c->grid)
+        return fail(c, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(!c->have_params)
+        return fail(c, LFI_EINVAL, "lfi_set_params has not been called");
+    if(method != LFI_METHOD_STD && method != LFI_METHOD_TEN_WM)
+        return fail(c, LFI_EINVAL, "The specified interpolation method does not exist!");
+    if(v0 < 0 || v1 > c->views_n || v0 >= v1)
+        return fail(c, LFI_EINVAL, "view range [v0, v1) outside [0, views)");
+    return LFI_OK;
+}
+
+void free_params(lfi_ctx *c)
+{
+    if(c->param_blob)
+        (void)hipFree(c->param_blob);
+    c->param_blob = nullptr;
+    c->have_params = false;
+}
+
+void free_views(lfi_ctx *c)
+{
+    if(c->own_views && c->views)
+        (void)hipFree(c->views);
+    c->views = nullptr;
+    c->own_views = false;
+    c->views_bytes = 0;
+}
+
+void free_grid(lfi_ctx *c)
+{
+    if(c->own_grid && c->grid)
+        (void)hipFree(c->grid);
+    c->grid = nullptr;
+    c->own_grid = false;
+    c->grid_bytes = 0;
+    if(c->maps)
+        (void)hipFree(c->maps);
+    c->maps = nullptr;
+    if(c->prequant)
+        (void)hipFree(c->prequant);
+    c->prequant = nullptr;
+}
+
+} // namespace
+
+extern "C" {
+
+int lfi_abi_version(void)
+{
+    return LFI_ABI_VERSION;
+}
+
+int lfi_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if(e != hipSuccess)
+    {
+        g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+        return LFI_ENODEVICE;
+    }
+    return n;
+}
+
+const char *lfi_last_error(const lfi_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int lfi_create(int device, lfi_ctx **out_ctx)
+{
+    if(!out_ctx)
+        return fail(nullptr, LFI_EINVAL, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if(e != hipSuccess || n <= 0)
+        return fail(nullptr, LFI_ENODEVICE,
+                    std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                        "); this library has no CPU fallback");
+    if(device < 0 || device >= n)
+        return fail(nullptr, LFI_EINVAL, "device index out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if(e != hipSuccess)
+        return fail(nullptr, LFI_EHIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if(std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, LFI_ENODEVICE,
+                    std::string("device is ") + prop.gcnArchName + "; the kernels in this library are built for gfx950 only");
+    lfi_ctx *c = new lfi_ctx();
+    c->device = device;
+    if(hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+    {
+        delete c;
+        return fail(nullptr, LFI_EHIP, "could not create stream/events on the device");
+    }
+    c->stream = c->own_stream;
+    *out_ctx = c;
+    return LFI_OK;
+}
+
+int lfi_destroy(lfi_ctx *ctx)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_params(ctx);
+    free_views(ctx);
+    free_grid(ctx);
+    if(ctx->ev0)
+        (void)hipEventDestroy(ctx->ev0);
+    if(ctx->ev1)
+        (void)hipEventDestroy(ctx->ev1);
+    if(ctx->own_stream)
+        (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return LFI_OK;
+}
+
+int lfi_set_stream(lfi_ctx *ctx, void *hip_stream)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return LFI_OK;
+}
+
+int lfi_set_grid(lfi_ctx *ctx, int cols, int rows, int width, int height)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(cols < 1 || rows < 1 || width < 1 || height < 1)
+        return fail(ctx, LFI_EINVAL, "grid dimensions must be positive");
+    if((long)cols * rows > LFI_MAX_IMAGES)
+        return fail(ctx, LFI_EINVAL, "more than LFI_MAX_IMAGES (256) grid images");
+    if((size_t)width * height > (size_t)1 << 28)
+        return fail(ctx, LFI_EINVAL, "image too large");
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_params(ctx);
+    free_views(ctx);
+    free_grid(ctx);
+    ctx->cols = cols;
+    ctx->rows = rows;
+    ctx->n = cols * rows;
+    ctx->width = width;
+    ctx->height = height;
+    ctx->grid_bytes = plane_bytes(ctx) * ctx->n;
+    LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->grid), ctx->grid_bytes));
+    ctx->own_grid = true;
+    LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->maps), plane_bytes(ctx) * 2));
+    LFI_HIP(ctx, hipMemsetAsync(ctx->maps, 0, plane_bytes(ctx) * 2, ctx->stream));
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LFI_OK;
+}
+
+int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_bytes)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->grid)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(g < 0 || g >= ctx->n || !rgba || pitch_bytes < (size_t)ctx->width * 4)
+        return fail(ctx, LFI_EINVAL, "bad image index, pointer or pitch");
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipMemcpy2DAsync(ctx->grid + plane_bytes(ctx) * g, (size_t)ctx->width * 4, rgba, pitch_bytes,
+                                  (size_t)ctx->width * 4, ctx->height, hipMemcpyHostToDevice, ctx->stream));
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LFI_OK;
+}
+
+int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->n)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(!device_ptr || bytes < plane_bytes(ctx) * ctx->n)
+        return fail(ctx, LFI_EINVAL, "attached grid buffer is NULL or smaller than N*H*W*4 bytes");
+    if(reinterpret_cast<uintptr_t>(device_ptr) % 16)
+        return fail(ctx, LFI_EINVAL, "attached grid buffer must be 16-byte aligned");
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if(ctx->own_grid && ctx->grid)
+        (void)hipFree(ctx->grid);
+    ctx->grid = static_cast<uint8_t *>(device_ptr);
+    ctx->own_grid = false;
+    ctx->grid_bytes = bytes;
+    return LFI_OK;
+}
+
+int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes)
+{
+    if(!ctx || !out_ptr)
+        return LFI_EINVAL;
+    *out_ptr = ctx->grid;
+    if(out_bytes)
+        *out_bytes = ctx->grid ? plane_bytes(ctx) * ctx->n : 0;
+    return LFI_OK;
+}
+
+int lfi_fill_synthetic(lfi_ctx *ctx, uint32_t seed)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->grid)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(int rc = bind(ctx))
+        return rc;
+    hipLaunchKernelGGL(lfi::fill_synthetic, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, ctx->n, ctx->width,
+                       ctx->height, seed);
+    LFI_HIP(ctx, hipGetLastError());
+    return LFI_OK;
+}
+
+int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->n)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(!p || p->views < 1 || !p->focused_offsets || !p->offsets || !p->weights_fp16)
+        return fail(ctx, LFI_EINVAL, "lfi_params: views < 1 or a required array is NULL");
+    if(p->n_focus_ids < 0 || p->n_focus_ids > LFI_MAX_FOCUS_IDS || (p->n_focus_ids > 0 && !p->focus_map_ids))
+        return fail(ctx, LFI_EINVAL, "lfi_params: bad focus_map_ids");
+    for(int i = 0; i < p->n_focus_ids; i++)
+        if(p->focus_map_ids[i] < 0 || p->focus_map_ids[i] >= ctx->n)
+            return fail(ctx, LFI_EINVAL, "lfi_params: focus_map_ids entry outside the grid");
+    if(p->views > 4096)
+        return fail(ctx, LFI_EINVAL, "lfi_params: more than 4096 views");
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    const int n = ctx->n, V = p->views;
+    const int k_pad = (n + 15) / 16 * 16;
+    // 64 spare rows: a view range may start anywhere, and a wave always reads whole 32-row tiles
+    const int v_pad = (V + 63) / 64 * 64 + 64;
+    const bool views_changed = V != ctx->views_n;
+
+    // host staging of the padded arrays, one blob
+    const size_t off_focused = 0;
+    const size_t off_offsets = off_focused + sizeof(lfi_int2) * k_pad;
+    const size_t off_w16 = off_offsets + sizeof(lfi_float2) * k_pad;
+    const size_t off_w32 = (off_w16 + sizeof(uint16_t) * (size_t)v_pad * k_pad + 15) / 16 * 16;
+    const size_t off_w32t = off_w32 + sizeof(float) * (size_t)v_pad * k_pad;
+    const size_t off_ids = off_w32t + sizeof(float) * (size_t)v_pad * k_pad;
+    const size_t total = off_ids + sizeof(int32_t) * LFI_MAX_FOCUS_IDS;
+    std::vector<uint8_t> blob(total, 0);
+    std::memcpy(blob.data() + off_focused, p->focused_offsets, sizeof(lfi_int2) * n);
+    std::memcpy(blob.data() + off_offsets, p->offsets, sizeof(lfi_float2) * n);
+    uint16_t *w16 = reinterpret_cast<uint16_t *>(blob.data() + off_w16);
+    float *w32 = reinterpret_cast<float *>(blob.data() + off_w32);
+    float *w32t = reinterpret_cast<float *>(blob.data() + off_w32t);
+    for(int v = 0; v < V; v++)
+        for(int g = 0; g < n; g++)
+        {
+            const uint16_t h = p->weights_fp16[(size_t)v * n + g];
+            const float f = static_cast<float>(__builtin_bit_cast(_Float16, h)); // half → float is exact
+            w16[(size_t)v * k_pad + g] = h;
+            w32[(size_t)v * k_pad + g] = f;
+            w32t[(size_t)g * v_pad + v] = f;
+        }
+    if(p->n_focus_ids)
+        std::memcpy(blob.data() + off_ids, p->focus_map_ids, sizeof(int32_t) * p->n_focus_ids);
+
+    free_params(ctx);
+    LFI_HIP(ctx, hipMalloc(&ctx->param_blob, total));
+    LFI_HIP(ctx, hipMemcpy(ctx->param_blob, blob.data(), total, hipMemcpyHostToDevice));
+    uint8_t *base = static_cast<uint8_t *>(ctx->param_blob);
+    ctx->d_focused = reinterpret_cast<lfi_int2 *>(base + off_focused);
+    ctx->d_offsets = reinterpret_cast<lfi_float2 *>(base + off_offsets);
+    ctx->d_w16 = reinterpret_cast<uint16_t *>(base + off_w16);
+    ctx->d_w32 = reinterpret_cast<float *>(base + off_w32);
+    ctx->d_w32t = reinterpret_cast<float *>(base + off_w32t);
+    ctx->d_ids = reinterpret_cast<int32_t *>(base + off_ids);
+    ctx->k_pad = k_pad;
+    ctx->v_pad = v_pad;
+    ctx->views_n = V;
+    ctx->n_focus_ids = p->n_focus_ids;
+    ctx->focus = p->focus;
+    ctx->range = p->range;
+    ctx->radius[0] = std::max(p->block_radius[0], 1);
+    ctx->radius[1] = std::max(p->block_radius[1], 1);
+    ctx->flags = p->flags;
+
+    if(views_changed || !ctx->views)
+    {
+        const bool was_attached = ctx->views && !ctx->own_views;
+        if(!(was_attached && ctx->views_bytes >= plane_bytes(ctx) * V))
+        {
+            free_views(ctx);
+            ctx->views_bytes = plane_bytes(ctx) * V;
+            LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->views), ctx->views_bytes));
+            ctx->own_views = true;
+        }
+    }
+    ctx->have_params = true;
+    return LFI_OK;
+}
+
+int lfi_attach_views(lfi_ctx *ctx, void *device_ptr, size_t bytes)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->have_params)
+        return fail(ctx, LFI_EINVAL, "lfi_set_params has not been called");
+    if(!device_ptr || bytes < plane_bytes(ctx) * ctx->views_n)
+        return fail(ctx, LFI_EINVAL, "attached view buffer is NULL or smaller than V*H*W*4 bytes");
+    if(reinterpret_cast<uintptr_t>(device_ptr) % 16)
+        return fail(ctx, LFI_EINVAL, "attached view buffer must be 16-byte aligned");
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_views(ctx);
+    ctx->views = static_cast<uint8_t *>(device_ptr);
+    ctx->views_bytes = bytes;
+    return LFI_OK;
+}
+
+int lfi_views_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes)
+{
+    if(!ctx || !out_ptr)
+        return LFI_EINVAL;
+    *out_ptr = ctx->views;
+    if(out_bytes)
+        *out_bytes = ctx->views ? plane_bytes(ctx) * ctx->views_n : 0;
+    return LFI_OK;
+}
+
+int lfi_focus_map(lfi_ctx *ctx)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->grid || !ctx->have_params)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid / lfi_set_params have not been called");
+    if(ctx->n_focus_ids < 1)
+        return fail(ctx, LFI_EINVAL, "no focus_map_ids in the parameters");
+    if(!(ctx->range > 0.0f))
+        return fail(ctx, LFI_EINVAL, "focus range must be > 0 for the focus map");
+    if(int rc = bind(ctx))
+        return rc;
+    const KernelArgs a = make_args(ctx, 0, ctx->views_n, LFI_METHOD_STD);
+    hipLaunchKernelGGL(lfi::focus_estimate, pixel_grid(ctx), dim3(256), 0, ctx->stream, a);
+    LFI_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(lfi::focus_filter, pixel_grid(ctx), dim3(256), 0, ctx->stream, a);
+    LFI_HIP(ctx, hipGetLastError());
+    return LFI_OK;
+}
+
+int lfi_render(lfi_ctx *ctx, int method, int all_focus, int v0, int v1)
+{
+    if(int rc = check_render_args(ctx, method, v0, v1))
+        return rc;
+    if(int rc = bind(ctx))
+        return rc;
+    const KernelArgs a = make_args(ctx, v0, v1, method);
+    return launch_blend(ctx, method, all_focus, a);
+}
+
+int lfi_sync(lfi_ctx *ctx)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LFI_OK;
+}
+
+int lfi_timer_start(lfi_ctx *ctx)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return LFI_OK;
+}
+
+int lfi_timer_stop(lfi_ctx *ctx, float *out_ms)
+{
+    if(!ctx || !out_ms)
+        return LFI_EINVAL;
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    LFI_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    LFI_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+    return LFI_OK;
+}
+
+int lfi_benchmark(lfi_ctx *ctx, int method, int all_focus, int v0, int v1, int warmup, int runs, lfi_bench_stats *out)
+{
+    if(int rc = check_render_args(ctx, method, v0, v1))
+        return rc;
+    if(!out || runs < 1 || warmup < 0)
+        return fail(ctx, LFI_EINVAL, "lfi_benchmark: runs must be ≥ 1 and out_stats non-NULL");
+    if(int rc = bind(ctx))
+        return rc;
+    const KernelArgs a = make_args(ctx, v0, v1, method);
+    for(int i = 0; i < warmup; i++)
+        if(int rc = launch_blend(ctx, method, all_focus, a))
+            return rc;
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<float> t(runs);
+    for(int i = 0; i < runs; i++)
+    {
+        LFI_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        if(int rc = launch_blend(ctx, method, all_focus, a))
+            return rc;
+        LFI_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        LFI_HIP(ctx, hipEventSynchronize(ctx->ev1));
+        LFI_HIP(ctx, hipEventElapsedTime(&t[i], ctx->ev0, ctx->ev1));
+    }
+    float b2b = 0;
+    LFI_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for(int i = 0; i < runs; i++)
+        if(int rc = launch_blend(ctx, method, all_focus, a))
+            return rc;
+    LFI_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    LFI_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    LFI_HIP(ctx, hipEventElapsedTime(&b2b, ctx->ev0, ctx->ev1));
+    std::vector<float> s = t;
+    std::sort(s.begin(), s.end());
+    double sum = 0;
+    for(float x : t)
+        sum += x;
+    out->runs = runs;
+    out->mean_ms = float(sum / runs);
+    out->median_ms = (runs & 1) ? s[runs / 2] : 0.5f * (s[runs / 2 - 1] + s[runs / 2]);
+    out->min_ms = s.front();
+    out->max_ms = s.back();
+    out->back_to_back_ms = b2b / runs;
+    return LFI_OK;
+}
+
+int lfi_download_view(lfi_ctx *ctx, int v, uint8_t *rgba, size_t pitch_bytes)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->views || !ctx->have_params)
+        return fail(ctx, LFI_EINVAL, "nothing rendered yet");
+    if(v < 0 || v >= ctx->views_n || !rgba || pitch_bytes < (size_t)ctx->width * 4)
+        return fail(ctx, LFI_EINVAL, "bad view index, pointer or pitch");
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipMemcpy2DAsync(rgba, pitch_bytes, ctx->views + plane_bytes(ctx) * v, (size_t)ctx->width * 4,
+                                  (size_t)ctx->width * 4, ctx->height, hipMemcpyDeviceToHost, ctx->stream));
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LFI_OK;
+}
+
+int lfi_download_map(lfi_ctx *ctx, int k, uint8_t *rgba, size_t pitch_bytes)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->maps)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(k < 0 || k > 1 || !rgba || pitch_bytes < (size_t)ctx->width * 4)
+        return fail(ctx, LFI_EINVAL, "bad map index, pointer or pitch");
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipMemcpy2DAsync(rgba, pitch_bytes, ctx->maps + plane_bytes(ctx) * k, (size_t)ctx->width * 4,
+                                  (size_t)ctx->width * 4, ctx->height, hipMemcpyDeviceToHost, ctx->stream));
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LFI_OK;
+}
+
+int lfi_upload_map(lfi_ctx *ctx, int k, const uint8_t *rgba, size_t pitch_bytes)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->maps)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(k < 0 || k > 1 || !rgba || pitch_bytes < (size_t)ctx->width * 4)
+        return fail(ctx, LFI_EINVAL, "bad map index, pointer or pitch");
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipMemcpy2DAsync(ctx->maps + plane_bytes(ctx) * k, (size_t)ctx->width * 4, rgba, pitch_bytes,
+                                  (size_t)ctx->width * 4, ctx->height, hipMemcpyHostToDevice, ctx->stream));
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LFI_OK;
+}
+
+const char *lfi_list_variants(int method)
+{
+    static std::string ten, std_;
+    if(ten.empty())
+    {
+        for(const auto &v : kTenVariants)
+            ten += std::string(ten.empty() ? "" : ",") + v.name;
+        for(const auto &v : kStdVariants)
+            std_ += std::string(std_.empty() ? "" : ",") + v.name;
+    }
+    if(method == LFI_METHOD_TEN_WM)
+        return ten.c_str();
+    if(method == LFI_METHOD_STD)
+        return std_.c_str();
+    return "";
+}
+
+int lfi_set_variant(lfi_ctx *ctx, int method, const char *name)
+{
+    if(!ctx || !name)
+        return LFI_EINVAL;
+    const bool is_auto = std::strcmp(name, "auto") == 0;
+    if(method == LFI_METHOD_TEN_WM)
+    {
+        if(is_auto)
+        {
+            ctx->ten_variant = 0;
+            return LFI_OK;
+        }
+        for(size_t i = 0; i < sizeof(kTenVariants) / sizeof(kTenVariants[0]); i++)
+            if(std::strcmp(name, kTenVariants[i].name) == 0)
+            {
+                ctx->ten_variant = int(i);
+                return LFI_OK;
+            }
+    }
+    else if(method == LFI_METHOD_STD)
+    {
+        if(is_auto)
+        {
+            ctx->std_variant = 0;
+            return LFI_OK;
+        }
+        for(size_t i = 0; i < sizeof(kStdVariants) / sizeof(kStdVariants[0]); i++)
+            if(std::strcmp(name, kStdVariants[i].name) == 0)
+            {
+                ctx->std_variant = int(i);
+                return LFI_OK;
+            }
+    }
+    return fail(ctx, LFI_EINVAL, std::string("unknown kernel variant ") + name);
+}
+
+int lfi_download_coords(lfi_ctx *ctx, int g, int all_focus, int map_index, lfi_int2 *out_hw)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->grid || !ctx->have_params)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid / lfi_set_params have not been called");
+    if(g < 0 || g >= ctx->n || !out_hw || map_index < 0 || map_index > 1)
+        return fail(ctx, LFI_EINVAL, "bad image index, map index or pointer");
+    if(int rc = bind(ctx))
+        return rc;
+    const size_t bytes = sizeof(lfi_int2) * (size_t)ctx->width * ctx->height;
+    lfi_int2 *d = nullptr;
+    LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), bytes));
+    KernelArgs a = make_args(ctx, 0, ctx->views_n, LFI_METHOD_STD);
+    a.map_index = map_index;
+    hipLaunchKernelGGL(lfi::dump_coords, pixel_grid(ctx), dim3(256), 0, ctx->stream, a, g, all_focus, d);
+    hipError_t e = hipGetLastError();
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(out_hw, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    LFI_HIP(ctx, e);
+    return LFI_OK;
+}
+
+int lfi_download_prequant(lfi_ctx *ctx, int method, int all_focus, int v, float *out_hw3)
+{
+    if(int rc = check_render_args(ctx, method, v, v + 1))
+        return rc;
+    if(!out_hw3)
+        return fail(ctx, LFI_EINVAL, "out_hw3 is NULL");
+    if(int rc = bind(ctx))
+        return rc;
+    const size_t bytes = sizeof(float) * 3 * (size_t)ctx->width * ctx->height;
+    if(!ctx->prequant)
+        LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->prequant), bytes));
+    KernelArgs a = make_args(ctx, v, v + 1, method);
+    a.prequant = ctx->prequant;
+    a.prequant_view = v;
+    if(int rc = launch_blend(ctx, method, all_focus, a))
+        return rc;
+    LFI_HIP(ctx, hipMemcpyAsync(out_hw3, ctx->prequant, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LFI_OK;
+}
+
+int lfi_debug_mfma_f16(lfi_ctx *ctx, const uint16_t *a_32x16, const uint16_t *b_16x32, float *c_32x32)
+{
+    if(!ctx || !a_32x16 || !b_16x32 || !c_32x32)
+        return LFI_EINVAL;
+    if(int rc = bind(ctx))
+        return rc;
+    uint8_t *d = nullptr;
+    LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), 1024 + 1024 + 4096));
+    hipError_t e = hipMemcpyAsync(d, a_32x16, 1024, hipMemcpyHostToDevice, ctx->stream);
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(d + 1024, b_16x32, 1024, hipMemcpyHostToDevice, ctx->stream);
+    if(e == hipSuccess)
+    {
+        hipLaunchKernelGGL(lfi::probe_mfma_f16, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<const uint16_t *>(d),
+                           reinterpret_cast<const uint16_t *>(d + 1024), reinterpret_cast<float *>(d + 2048));
+        e = hipGetLastError();
+    }
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(c_32x32, d + 2048, 4096, hipMemcpyDeviceToHost, ctx->stream);
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    LFI_HIP(ctx, e);
+    return LFI_OK;
+}
+
+} // extern "C"
