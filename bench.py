@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's headline metric on MI355X: novel views/s (+ Gpix/s) of the TEN_WM hot path,
+8×8 light field @1920×1080, 64-view trajectory per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one launch of the blend kernel over the synthetic grid resident in HBM = 64 novel views of 1920×1080 from
+64 input images on each GPU.  One process per GPU.  Multi-GPU: the trajectory has 64·N views, rank r renders views
+[64r, 64r+64) — the path shards over views with no data-path collective (weak scaling: per-GPU work is fixed); the
+input grid is generated on rank 0 and broadcast ONCE over RCCL/xGMI before the timed region.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     — HBM roofline of the blend kernel: algorithmic bytes 4·W·H·(N_images + V) per launch ÷ the kernel's
+                 average launch time measured with HIP events on the launch stream (through the C-ABI timer);
+  cpu_baseline — the CPU oracle (a port of the reference's STD arithmetic) timed on the host cores on the same
+                 workload (N = 1 only).  oracle/ is used here ONLY as that baseline, never in the GPU path.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+COLS, ROWS, WIDTH, HEIGHT = 8, 8, 1920, 1080
+VIEWS_PER_GPU = 64
+TRAJECTORY, FOCUS, ASPECT, EFFECT = "0.0,0.0,1.0,1.0", 0.23, 1.783, 3.0   # reference README.md:7
+SEED = 0x1F1F
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(hp, threads: int) -> dict:
+    """The oracle's scalar STD blend on one full step of the same workload, on `threads` host cores."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import lfi_oracle_c as oc
+    oc.build()
+    n = COLS * ROWS
+    lf = np.empty((n, HEIGHT, WIDTH, 4), dtype=np.uint8)
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda g: lf.__setitem__(g, oc.synthetic_plane(g, WIDTH, HEIGHT, SEED)), range(n)))
+    t0 = time.perf_counter()
+    oc.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, threads=threads)
+    dt = time.perf_counter() - t0
+    v = hp.weights.shape[0]
+    return {"value": v / dt, "unit": "views/s", "cores": threads, "kind": "port",
+            "sample": f"1 step: {v} views of {WIDTH}x{HEIGHT} from {n} images, scalar fp32 FMA weighted mean "
+                      f"(oracle STD), {dt:.2f} s wall",
+            "gpix_per_s": v * WIDTH * HEIGHT / dt / 1e9}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--method", default="TEN_WM", choices=["TEN_WM", "STD"])
+    ap.add_argument("--variant", default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run "
+                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
+            return 2
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import lfinterpolator_amd as L
+
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_images = COLS * ROWS
+    ctx = L.Context(local_rank)
+    ctx.set_grid(COLS, ROWS, WIDTH, HEIGHT)
+    # input planes live in a torch tensor so that RCCL (torch.distributed "nccl") can broadcast into them
+    grid = torch.empty((n_images, HEIGHT, WIDTH, 4), dtype=torch.uint8, device=dev)
+    ctx.attach_grid(grid.data_ptr(), grid.numel())
+    stream = torch.cuda.Stream(device=dev)
+    ctx.set_stream(stream.cuda_stream)
+    if rank == 0:
+        ctx.fill_synthetic(SEED)
+        ctx.sync()
+    if world > 1:
+        dist.broadcast(grid, src=0)  # the one collective of the job: 531 MB over xGMI, outside the timed region
+        torch.cuda.synchronize()
+
+    # host parameters for the whole trajectory; each rank keeps its own rows of the weight matrix
+    total_views = VIEWS_PER_GPU * world
+    hp_all = L.build_params(COLS, ROWS, WIDTH, HEIGHT, TRAJECTORY, FOCUS, 0.0, EFFECT, ASPECT, total_views)
+    hp = hp_all.rows(rank * VIEWS_PER_GPU, (rank + 1) * VIEWS_PER_GPU)
+    ctx.set_params(hp)
+    views = torch.empty((VIEWS_PER_GPU, HEIGHT, WIDTH, 4), dtype=torch.uint8, device=dev)
+    ctx.attach_views(views.data_ptr(), views.numel())
+    ctx.set_variant(args.method, args.variant)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.render(args.method)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()                      # HIP event on the launch stream
+    for _ in range(args.steps):
+        ctx.render(args.method)
+    kernel_ms = ctx.timer_stop()           # HIP event + synchronise: time of the K launches on that stream
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed, kernel_ms / 1e3], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed_max, kernel_s_max = float(t[0]), float(t[1])
+
+    # cheap sanity check that the timed launches rendered something: alpha must be 255 everywhere, RGB not constant
+    sample = views[0, HEIGHT // 2, :64].cpu().numpy()
+    assert (sample[:, 3] == 255).all() and sample[:, :3].std() > 0, "render produced no image"
+
+    if rank == 0:
+        value = total_views * args.steps / elapsed_max
+        b_alg = 4.0 * WIDTH * HEIGHT * (n_images + VIEWS_PER_GPU)       # bytes per launch per GPU
+        t_launch = kernel_s_max / args.steps
+        achieved = b_alg / t_launch / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")           # PMC-derived HBM bytes per launch, if measured
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.method}/{args.variant}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "novel views/sec + Gpix/sec, 8x8 LF @1080p TEN_WM" if args.method == "TEN_WM"
+                      else "novel views/sec + Gpix/sec, 8x8 LF @1080p STD",
+            "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16" if args.method == "TEN_WM" else "f32", "data": "synthetic",
+            "config": {"workload": f"{COLS}x{ROWS} LF @{WIDTH}x{HEIGHT}, {VIEWS_PER_GPU}-view -t trajectory per GPU, "
+                                   f"-m {args.method}, -f {FOCUS} -a {ASPECT} -s {EFFECT:g}",
+                       "views_per_gpu": VIEWS_PER_GPU, "images": n_images, "variant": args.variant,
+                       "parallelism": f"views sharded over {world} GPU(s), grid broadcast once (RCCL)"},
+            "gpix_per_s": value * WIDTH * HEIGHT / 1e9,
+            "kernel_ms_per_launch": t_launch * 1e3,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": b_alg, "frac_of_measured_copy_6290": achieved / 6290.0,
+                         "mfma_frac_of_2500_tflops": 6.0 * n_images * VIEWS_PER_GPU * WIDTH * HEIGHT / t_launch / 2.5e15},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, 16)
+            line["cpu_baseline"] = cpu_baseline(hp, threads)
+        print(json.dumps(line), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

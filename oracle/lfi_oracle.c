@@ -269,19 +269,24 @@ uint32_t lfo_hash32(uint32_t seed, uint32_t g, uint32_t y, uint32_t x, uint32_t 
     return h;
 }
 
+void lfo_fill_synthetic_plane(uint8_t *plane, int g, int width, int height, uint32_t seed)
+{
+    for(int y = 0; y < height; y++)
+    {
+        uint8_t *row = plane + (size_t)y * (size_t)width * 4;
+        for(int x = 0; x < width; x++)
+        {
+            for(int c = 0; c < 3; c++)
+                row[4 * x + c] = (uint8_t)(lfo_hash32(seed, (uint32_t)g, (uint32_t)y, (uint32_t)x, (uint32_t)c) >> 24);
+            row[4 * x + 3] = 255;
+        }
+    }
+}
+
 void lfo_fill_synthetic(uint8_t *planes, int n_images, int width, int height, uint32_t seed)
 {
     for(int g = 0; g < n_images; g++)
-        for(int y = 0; y < height; y++)
-        {
-            uint8_t *row = planes + ((size_t)g * height + y) * (size_t)width * 4;
-            for(int x = 0; x < width; x++)
-            {
-                for(int c = 0; c < 3; c++)
-                    row[4 * x + c] = (uint8_t)(lfo_hash32(seed, (uint32_t)g, (uint32_t)y, (uint32_t)x, (uint32_t)c) >> 24);
-                row[4 * x + 3] = 255;
-            }
-        }
+        lfo_fill_synthetic_plane(planes + (size_t)g * height * (size_t)width * 4, g, width, height, seed);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -58,6 +58,7 @@ void lfo_block_radius(int width, int height, int32_t out_xy[2]);                
 /* ---- synthetic light field; not from the reference ---- */
 uint32_t lfo_hash32(uint32_t seed, uint32_t g, uint32_t y, uint32_t x, uint32_t c);
 void lfo_fill_synthetic(uint8_t *planes, int n_images, int width, int height, uint32_t seed);
+void lfo_fill_synthetic_plane(uint8_t *plane, int g, int width, int height, uint32_t seed);
 
 /* ---- device-side arithmetic: src/kernels.cu ---- */
 

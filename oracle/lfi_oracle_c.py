@@ -79,6 +79,8 @@ def _declare(l: C.CDLL) -> None:
     l.lfo_hash32.argtypes = [C.c_uint32] * 5
     l.lfo_fill_synthetic.restype = None
     l.lfo_fill_synthetic.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_uint32]
+    l.lfo_fill_synthetic_plane.restype = None
+    l.lfo_fill_synthetic_plane.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_uint32]
     l.lfo_warp_coords.restype = None
     l.lfo_warp_coords.argtypes = [C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_float, C.c_float,
                                   C.c_int, C.c_int, _vp]
@@ -164,6 +166,12 @@ def synthetic_lf(n_images, width, height, seed):
     return out
 
 
+def synthetic_plane(g, width, height, seed):
+    out = np.empty((height, width, 4), dtype=np.uint8)
+    lib().lfo_fill_synthetic_plane(_p(out), g, width, height, seed)
+    return out
+
+
 # ---- device-side arithmetic ----------------------------------------------------------------------------------
 
 def _rows(height, threads):
@@ -172,8 +180,12 @@ def _rows(height, threads):
     return [(int(edges[i]), int(edges[i + 1])) for i in range(threads) if edges[i + 1] > edges[i]]
 
 
-def _run_rows(fn, height, threads):
-    """ctypes drops the GIL during the call, so row bands run on `threads` host cores."""
+def _run_rows(fn, height, threads, rows=None):
+    """ctypes drops the GIL during the call, so row bands run on `threads` host cores.
+    rows=(y0, y1) restricts the computation to that band (the rest of the output stays zero)."""
+    if rows is not None:
+        fn(int(rows[0]), int(rows[1]))
+        return
     bands = _rows(height, threads)
     if len(bands) == 1:
         fn(*bands[0])
@@ -208,22 +220,22 @@ def _blend_args(lf, focused, offs, weights_vn, v0, v1, all_focus, map_plane, foc
 
 
 def blend_std(lf, focused, offs, weights_vn, v0=0, v1=None, all_focus=False, map_plane=None, focus=0.0, rng=0.0,
-              return_prequant=False, threads=1):
+              return_prequant=False, threads=1, rows=None):
     keep, args, (n, h, w, views, v1) = _blend_args(lf, focused, offs, weights_vn, v0, v1, all_focus, map_plane, focus,
                                                    rng)
     out = np.zeros((views, h, w, 4), dtype=np.uint8)
     pre = np.zeros((views, h, w, 3), dtype=np.float32) if return_prequant else None
-    _run_rows(lambda a, b: lib().lfo_blend_std(*args, a, b, _p(out), _p(pre)), h, threads)
+    _run_rows(lambda a, b: lib().lfo_blend_std(*args, a, b, _p(out), _p(pre)), h, threads, rows)
     return (out, pre) if return_prequant else out
 
 
 def blend_ten(lf, focused, offs, weights_vn, model=TEN_M16, v0=0, v1=None, all_focus=False, map_plane=None, focus=0.0,
-              rng=0.0, return_prequant=False, threads=1):
+              rng=0.0, return_prequant=False, threads=1, rows=None):
     keep, args, (n, h, w, views, v1) = _blend_args(lf, focused, offs, weights_vn, v0, v1, all_focus, map_plane, focus,
                                                    rng)
     out = np.zeros((views, h, w, 4), dtype=np.uint8)
     pre = np.zeros((views, h, w, 3), dtype=np.float32) if return_prequant else None
-    _run_rows(lambda a, b: lib().lfo_blend_ten(*args, model, a, b, _p(out), _p(pre)), h, threads)
+    _run_rows(lambda a, b: lib().lfo_blend_ten(*args, model, a, b, _p(out), _p(pre)), h, threads, rows)
     return (out, pre) if return_prequant else out
 
 

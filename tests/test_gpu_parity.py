@@ -1,0 +1,256 @@
+"""GPU (-m gpu): the HIP path through the C-ABI against the CPU oracle and the golden fixtures.
+
+Contract:
+  * integer / float warp coordinates: bit-exact;
+  * STD: u8 outputs and fp32 accumulators bit-exact;
+  * TEN_WM: u8 within 1 LSB of the fp16-accumulate model M16, pre-quantisation within 1e-3 (normalised to [0,1]) of
+    the exact fp64 blend; the per-batch debug mode reproduces M16.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, SEED, SMALL_CASES
+
+pytestmark = pytest.mark.gpu
+
+TEN_TOL_LSB = 1          # |u8(HIP) - u8(M16)| ≤ 1
+TEN_TOL_PREQUANT = 1e-3  # |prequant(HIP)/255 - exact/255| ≤ 1e-3
+
+
+def _ctx(gpu, cols, rows, W, H, hp, lf=None, seed=SEED, flags=0):
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    if lf is None:
+        ctx.fill_synthetic(seed)
+    else:
+        ctx.upload_grid(lf)
+    ctx.set_params(hp, flags)
+    return ctx
+
+
+def test_mfma_fragment_maps_and_fp16_subnormals(gpu):
+    """One v_mfma_f32_32x32x16_f16 on exact integer data with an asymmetric A: checks the A/B/D lane maps the kernels
+    rely on, and that fp16 subnormal operands (pixel bytes b·2^-24, tiny weights) are not flushed."""
+    ctx = gpu.Context(0)
+    a = np.zeros((32, 16), np.float16)
+    b = np.zeros((16, 32), np.float16)
+    for i in range(32):
+        for k in range(16):
+            a[i, k] = (i * 3 + k * 5) % 17 - 8      # small integers, asymmetric
+    for k in range(16):
+        for j in range(32):
+            b[k, j] = (k * 7 + j * 2) % 13 - 6
+    c = ctx.debug_mfma_f16(a.view(np.uint16), b.view(np.uint16))
+    assert (c == a.astype(np.float64) @ b.astype(np.float64)).all()
+    # subnormal pixels × normal weights, exact in fp32: one non-zero product per output element
+    a2 = np.zeros((32, 16), np.uint16)
+    b2 = np.zeros((16, 32), np.uint16)
+    for i in range(32):
+        a2[i, i % 16] = 0x3c00 - i * 13          # weights just below 1
+    for j in range(32):
+        b2[:, j] = (np.arange(16) * 16 + j * 7) % 256  # pixel bytes as fp16 subnormal bit patterns
+    c2 = ctx.debug_mfma_f16(a2, b2)
+    want = a2.view(np.float16).astype(np.float64) @ b2.view(np.float16).astype(np.float64)
+    assert (c2.astype(np.float64) == want).all()
+    # subnormal weights (effect 7 produces them) × subnormal pixels: 2^-24 · 255·2^-24, still exact in fp32
+    a3 = np.zeros((32, 16), np.uint16)
+    a3[:, 0] = np.arange(1, 33)
+    c3 = ctx.debug_mfma_f16(a3, b2)
+    want3 = a3.view(np.float16).astype(np.float64) @ b2.view(np.float16).astype(np.float64)
+    assert (c3.astype(np.float64) == want3).all()
+    ctx.close()
+
+
+def test_synthetic_fill_matches_oracle(gpu, oracle_c):
+    ctx = gpu.Context(0)
+    ctx.set_grid(3, 2, 37, 11)
+    ctx.fill_synthetic(1234)
+    ctx.sync()
+    hp = gpu.build_params(3, 2, 37, 11, "0,0,1,1", 0.0, 0.0, 3.0, 1.0, 6)
+    onehot = np.zeros((6, 6), np.uint16)
+    onehot[np.arange(6), np.arange(6)] = 0x3c00
+    hp.weights = onehot
+    hp.focused_offsets = np.zeros((6, 2), np.int32)
+    ctx.set_params(hp)
+    ctx.render("STD")
+    ctx.sync()
+    assert (ctx.download_views() == oracle_c.synthetic_lf(6, 37, 11, 1234)).all()
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", SMALL_CASES, ids=[c[0] for c in SMALL_CASES])
+def test_golden_fixtures(case, gpu, oracle_c):
+    name, cols, rows, W, H, V, traj, focus, aspect, effect = case
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    rng = float(g["range"])
+    hp = gpu.build_params(cols, rows, W, H, traj, focus, rng, effect, aspect, V)
+    assert (hp.weights == g["weights"]).all() and (hp.focused_offsets == g["focused"]).all()
+    ctx = _ctx(gpu, cols, rows, W, H, hp, lf=g["lf"])
+    exact = oracle_c.blend_f64(g["lf"], hp.focused_offsets, hp.offsets, hp.weights)
+    for variant in ctx.list_variants("STD"):
+        ctx.set_variant("STD", variant)
+        ctx.render("STD")
+        ctx.sync()
+        assert (ctx.download_views() == g["std"]).all(), variant
+    for variant in ctx.list_variants("TEN_WM"):
+        ctx.set_variant("TEN_WM", variant)
+        ctx.render("TEN_WM")
+        ctx.sync()
+        out = ctx.download_views()
+        assert np.abs(out.astype(int) - g["ten_m16"].astype(int)).max() <= TEN_TOL_LSB, variant
+        assert (out[..., 3] == 255).all()
+        # single rounding of an fp32 sum vs single rounding of the exact sum: equal except on razor-edge ties
+        assert (out != g["ten_exact"]).mean() < 1e-3, variant
+        for v in (0, V - 1):
+            pre = ctx.download_prequant("TEN_WM", v)
+            assert np.abs(pre / 255.0 - exact[v] / 255.0).max() <= TEN_TOL_PREQUANT, variant
+    # focus map + all-focus renders
+    ctx.set_variant("STD", "auto")
+    ctx.set_variant("TEN_WM", "auto")
+    ctx.focus_map()
+    ctx.sync()
+    assert (ctx.download_map(0) == g["map0"]).all()
+    assert (ctx.download_map(1) == g["map1"]).all()
+    for variant in ctx.list_variants("STD"):
+        ctx.set_variant("STD", variant)
+        ctx.render("STD", all_focus=True)
+        ctx.sync()
+        assert (ctx.download_views() == g["af_std"]).all(), variant
+    for variant in ctx.list_variants("TEN_WM"):
+        ctx.set_variant("TEN_WM", variant)
+        ctx.render("TEN_WM", all_focus=True)
+        ctx.sync()
+        assert np.abs(ctx.download_views().astype(int) - g["af_ten_m16"].astype(int)).max() <= TEN_TOL_LSB, variant
+    ctx.close()
+
+
+def test_warp_coordinates_bit_exact(gpu, oracle_c):
+    cols = rows = 8
+    W, H = 96, 40
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.22, 0.17, 7.0, 1.783, 8)
+    ctx = _ctx(gpu, cols, rows, W, H, hp)
+    map1 = (oracle_c.synthetic_lf(1, W, H, 99)[0]).copy()  # arbitrary per-pixel focus bytes
+    ctx.upload_map(1, map1)
+    for g in (0, 7, 27, 63):
+        assert (ctx.download_coords(g) == oracle_c.warp_coords(g, W, H, hp.focused_offsets, hp.offsets)).all()
+        got = ctx.download_coords(g, all_focus=True, map_index=1)
+        want = oracle_c.warp_coords(g, W, H, hp.focused_offsets, hp.offsets, True, map1, hp.focus, hp.range)
+        assert (got == want).all()
+    ctx.close()
+
+
+def test_std_accumulators_bit_exact_and_ten_per_batch_mode(gpu, oracle_c):
+    cols = rows = 8
+    W, H, V = 64, 48, 64
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.23, 0.0, 3.0, 1.783, V)
+    lf = oracle_c.synthetic_lf(64, W, H, SEED)
+    ctx = _ctx(gpu, cols, rows, W, H, hp)
+    _, pre = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, return_prequant=True)
+    for variant in ctx.list_variants("STD"):
+        ctx.set_variant("STD", variant)
+        for v in (0, 31, 63):
+            assert (ctx.download_prequant("STD", v) == pre[v]).all(), variant
+    ctx.close()
+    # debug numerics: fp16 re-rounding per 16-image batch reproduces the reference model M16
+    ctx = _ctx(gpu, cols, rows, W, H, hp, flags=gpu.LFI_FLAG_TEN_ROUND_PER_BATCH)
+    ctx.render("TEN_WM")
+    ctx.sync()
+    m16 = oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, model=oracle_c.TEN_M16)
+    assert (ctx.download_views() != m16).mean() < 1e-3
+    ctx.close()
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 130, 9, 64), (15, 15, 70, 6, 45), (3, 3, 256, 256, 1), (2, 5, 31, 33, 70),
+                                   (1, 1, 17, 5, 3), (8, 8, 512, 4, 130)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_ragged_shapes_all_variants(shape, gpu, oracle_c):
+    """width not a multiple of the pixel tile, N not a multiple of 16 (zero-padded K), views not a multiple of 32,
+    more than 64 views (several passes), 1 view (BASELINE config 1 shape 3×3@256²), 1×1 grid."""
+    cols, rows, W, H, V = shape
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.3, 0.0, 3.0, 1.5, V)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, SEED)
+    ctx = _ctx(gpu, cols, rows, W, H, hp)
+    std = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, threads=8)
+    m16 = oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, threads=8)
+    for variant in ctx.list_variants("STD"):
+        ctx.set_variant("STD", variant)
+        ctx.render("STD")
+        ctx.sync()
+        assert (ctx.download_views() == std).all(), variant
+    for variant in ctx.list_variants("TEN_WM"):
+        ctx.set_variant("TEN_WM", variant)
+        ctx.render("TEN_WM")
+        ctx.sync()
+        assert np.abs(ctx.download_views().astype(int) - m16.astype(int)).max() <= TEN_TOL_LSB, variant
+    ctx.close()
+
+
+def test_offsets_larger_than_image_and_subnormal_weights(gpu, oracle_c):
+    cols = rows = 15
+    W, H, V = 48, 20, 8
+    # focus 3.0: integer offsets up to ±(3·W) — every sample clamps to an edge for the outer images
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 3.0, 0.0, 7.0, 2.0223, V)
+    assert np.abs(hp.focused_offsets).max() > W
+    assert ((hp.weights & 0x7c00) == 0).any()  # fp16 subnormal weights present (-s 7)
+    lf = oracle_c.synthetic_lf(225, W, H, 5)
+    ctx = _ctx(gpu, cols, rows, W, H, hp, seed=5)
+    for variant in ctx.list_variants("STD"):
+        ctx.set_variant("STD", variant)
+        ctx.render("STD")
+        ctx.sync()
+        assert (ctx.download_views() == oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)).all()
+    m16 = oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights)
+    for variant in ctx.list_variants("TEN_WM"):
+        ctx.set_variant("TEN_WM", variant)
+        ctx.render("TEN_WM")
+        ctx.sync()
+        assert np.abs(ctx.download_views().astype(int) - m16.astype(int)).max() <= TEN_TOL_LSB
+    ctx.close()
+
+
+def test_view_range_sharding_is_exact(gpu):
+    """Rendering [v0,v1) ranges (what each rank of a multi-GPU job does) gives the bytes of the full render."""
+    cols = rows = 8
+    W, H, V = 128, 24, 64
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.23, 0.0, 3.0, 1.783, V)
+    ctx = _ctx(gpu, cols, rows, W, H, hp)
+    for method in ("STD", "TEN_WM"):
+        ctx.render(method)
+        ctx.sync()
+        full = ctx.download_views()
+        for v0, v1 in ((0, 8), (8, 16), (24, 56), (63, 64)):
+            ctx.render(method, v0=0, v1=V)  # refill
+            ctx.render(method, v0=v0, v1=v1)
+            ctx.sync()
+            assert (ctx.download_views(v0, v1) == full[v0:v1]).all()
+        # a rank that only owns rows [16,24) of the weight matrix
+        ctx2 = _ctx(gpu, cols, rows, W, H, hp.rows(16, 24))
+        ctx2.render(method)
+        ctx2.sync()
+        assert (ctx2.download_views() == full[16:24]).all()
+        ctx2.close()
+    ctx.close()
+
+
+def test_error_behaviour(gpu):
+    ctx = gpu.Context(0)
+    with pytest.raises(gpu.LfiError, match="lfi_set_grid"):
+        ctx.render("STD", v1=1)
+    ctx.set_grid(2, 2, 8, 8)
+    with pytest.raises(gpu.LfiError, match="lfi_set_params"):
+        ctx.render("STD", v1=1)
+    hp = gpu.build_params(2, 2, 8, 8, "0,0,1,1", 0.1, 0.0, 3.0, 1.0, 4)
+    ctx.set_params(hp)
+    with pytest.raises(gpu.LfiError, match="does not exist"):  # the reference's runtime_error text
+        ctx.render(7)
+    with pytest.raises(gpu.LfiError, match="view range"):
+        ctx.render("STD", v0=2, v1=9)
+    with pytest.raises(gpu.LfiError, match="range must be > 0"):
+        ctx.focus_map()
+    with pytest.raises(gpu.LfiError, match="unknown kernel variant"):
+        ctx.set_variant("STD", "nope")
+    with pytest.raises(gpu.LfiError):
+        ctx.set_grid(17, 17, 8, 8)  # more than 256 images
+    ctx.close()
