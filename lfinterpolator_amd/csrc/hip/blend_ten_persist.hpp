@@ -1,0 +1,286 @@
+// blend_ten_persist.hpp — TEN_WM as a persistent, double-buffered LDS-DMA pipeline (the production kernel).
+//
+// Measurements that shaped it (profiles/r01_notes.md): the memory system sustains this access pattern (64 shifted input
+// planes gathered, 64 output planes scattered) at ≈5.4–5.8 TB/s with trivial compute; a kernel that does
+// load-tile → barrier → compute → store once per workgroup exposes the whole HBM latency per tile (waves parked 84 % of
+// their life).  So each workgroup here is persistent and keeps a pipeline of "units" (one unit = one K-chunk of one pixel
+// tile for one view pass):
+//
+//      top of unit u:   s_waitcnt vmcnt(#stores of the previous epilogue)   → this wave's DMA pieces of unit u have landed,
+//                                                                             the previous tile's stores stay in flight
+//                       s_barrier                                           → everybody's pieces have landed AND everybody has
+//                                                                             finished reading the other buffer
+//                       issue LDS-DMA of unit u+1 into the other buffer     (pixels 32 KB + weight fragments 8 KB)
+//                       compute unit u from LDS (ds_read → v_perm → MFMA)
+//                       last chunk of the tile: packed-fp16 epilogue + 32 stores per wave
+//
+// One barrier per unit, reads of unit u+1 and writes of tile u-1 overlap the MFMA/VALU work of unit u inside the same
+// workgroup; two workgroups per CU (2 × 80 KB LDS) fill each other's gaps.
+//
+// The DMA instructions are issued from inline asm on purpose: hipcc would otherwise (correctly, but fatally for the
+// pipeline) wait for vmcnt(0) before the first ds_read after a global_load_lds it knows about.  Because they are invisible
+// to the compiler, the loop contains NO compiler-tracked global loads (offsets come through scalar loads = lgkmcnt, weights
+// through LDS), so the only s_waitcnt vmcnt in the loop is the hand-counted one above.  vmcnt retires in order and counts
+// stores, which is why the count of epilogue stores (a compile-time constant for full tiles, else we wait for everything)
+// appears in it.
+//
+// Contraction, operand maps, subnormal-pixel trick and packed epilogue: blend_ten.hpp / blend_ten_lds.hpp.
+// Replaces Kernels::Tensors::process<allFocus> (reference src/kernels.cu:398-461).
+#pragma once
+
+#include "blend_ten_lds.hpp"
+
+namespace lfi {
+
+// LDS-DMA from inline asm: lane l's 16 (4) bytes at gptr land at LDS byte address lds_addr + 16 l (4 l).
+// M0 carries the LDS base; it is written in the same statement that uses it (hipcc does not preserve M0 across statements).
+__device__ __forceinline__ void dma16(const void *gptr, uint32_t lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+}
+__device__ __forceinline__ void dma4(const void *gptr, uint32_t lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+}
+
+template <int MT, bool ALLFOCUS, bool NT_STORE>
+struct PersistCfg
+{
+    static constexpr int NW = 4;                 // waves per workgroup, side by side along the row
+    static constexpr int TPX = 128;              // pixels per tile: 32 per wave, one per lane column
+    static constexpr int KC = 64;                // images per chunk
+    static constexpr int VPP = MT * 32;          // views per pass
+    static constexpr int PX_DW = KC * TPX;       // dwords of pixels per buffer (32 KB)
+    static constexpr int W_DW = (KC / 8) * VPP * 4; // dwords of weight fragments per buffer: [k-octet][view] × 16 B
+    static constexpr int BUF_DW = PX_DW + W_DW;
+    static constexpr int STORES = MT * 16;       // epilogue stores per wave on a full tile
+};
+
+template <int MT, bool ALLFOCUS, bool NT_STORE>
+__global__ void __launch_bounds__(256, 2)
+    blend_ten_persist(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes)
+{
+    using C = PersistCfg<MT, ALLFOCUS, NT_STORE>;
+    constexpr int TPX = C::TPX, KC = C::KC, VPP = C::VPP, KS = KC / 16;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * C::BUF_DW];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int W = a.width, H = a.height;
+    const uint32_t *grid32 = reinterpret_cast<const uint32_t *>(a.grid);
+    const size_t plane_px = (size_t)W * (size_t)H;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr_t)lds)));
+    // the offset tables are read through the scalar cache (constant address space): wave-uniform, and counted by lgkmcnt, so
+    // they never touch the vmcnt bookkeeping of the pipeline
+    typedef const __attribute__((address_space(4))) int32_t *const_int_ptr;
+    typedef const __attribute__((address_space(4))) float *const_float_ptr;
+    const const_int_ptr c_focused = (const_int_ptr)(uintptr_t)a.focused;   // [g] = {x, y}
+    const const_float_ptr c_offsets = (const_float_ptr)(uintptr_t)a.offsets;
+
+    // ---- issue the LDS-DMA of one unit (tile t, view pass `pass`, chunk k0) into buffer b ------------------------------------
+    auto issue = [&](int t, int pass, int k0, int b) {
+        const int y = t / tiles_x;
+        const int x0 = (t - y * tiles_x) * TPX;
+        const int kc = min(KC, a.k_pad - k0);
+        const int kn = min(kc, a.n_images - k0);
+        const uint32_t px_addr = lds_base + uint32_t(b) * (C::BUF_DW * 4);
+        const uint32_t w_addr = px_addr + C::PX_DW * 4;
+        // weight fragments: one instruction per k-octet o: lane l ← W[v0 + pass*VPP + l][k0 + 8o … +7] (×2^15), 16 bytes,
+        // landing at slot o*VPP + l: the A-fragment reads of a k-step are then two contiguous 512-B runs (conflict-free)
+        for(int o = wave; 8 * o < kc; o += C::NW)
+        {
+            if(lane < VPP)
+            {
+                const uint16_t *src = a.w16s + (size_t)(a.v0 + pass * VPP + lane) * a.k_pad + k0 + 8 * o;
+                dma16(src, w_addr + uint32_t(o) * (VPP * 16));
+            }
+        }
+        if constexpr(!ALLFOCUS)
+        {
+            // pixels: 16 B/lane pieces, two images per instruction (half-wave hh ↔ image 2q+hh, lane column c ↔ pixels 4c…4c+3)
+            for(int q = wave; 2 * q < kn; q += C::NW)
+            {
+                const int g0 = k0 + 2 * q;                     // wave-uniform → scalar loads of the offsets
+                const int g1 = min(g0 + 1, k0 + kn - 1);       // odd tail: the second half reloads the last image
+                const lfi_int2 o0 = {c_focused[2 * g0], c_focused[2 * g0 + 1]}, o1 = {c_focused[2 * g1], c_focused[2 * g1 + 1]};
+                const int ox = h ? o1.x : o0.x, oy = h ? o1.y : o0.y;
+                const int g = h ? g1 : g0;
+                const int sy = clampi(y + oy, 0, H - 1);
+                const int sx = x0 + ox + 4 * r;
+                const bool inside = (sx >= 0) && (sx + 4 <= W) && (2 * q + 1 < kn || h == 0);
+                const bool all_inside = __builtin_amdgcn_ballot_w64(inside) == ~0ull;
+                if(all_inside)
+                    dma16(grid32 + (size_t)g * plane_px + (size_t)sy * W + sx, px_addr + uint32_t(q) * 1024u);
+                else
+                {
+                    // a run crosses the left/right border (or the tile is ragged): per-pixel clamp-to-edge addresses
+                    // (reference src/kernels.cu:125), 64 pixels per instruction
+#pragma unroll
+                    for(int img = 0; img < 2; img++)
+                    {
+                        if(2 * q + img >= kn)
+                            break;
+                        const lfi_int2 oo = img ? o1 : o0;
+                        const int syy = clampi(y + oo.y, 0, H - 1);
+                        const uint32_t *row = grid32 + (size_t)(g0 + img) * plane_px + (size_t)syy * W;
+#pragma unroll
+                        for(int s = 0; s < 2; s++)
+                        {
+                            const int sxx = clampi(x0 + oo.x + 64 * s + lane, 0, W - 1);
+                            dma4(row + sxx, px_addr + uint32_t(2 * q + img) * 512u + uint32_t(s) * 256u);
+                        }
+                    }
+                }
+            }
+        }
+        else
+        {
+            // all-focus: the warp depends on the pixel's own focus value (src/kernels.cu:78-82): per-pixel gather
+            const uint8_t *map_plane = a.maps + (size_t)a.map_index * plane_px * 4;
+            const float f0 = decode_focus(map_plane, W, H, x0 + lane, y, a.focus, a.range);
+            const float f1 = decode_focus(map_plane, W, H, x0 + 64 + lane, y, a.focus, a.range);
+            for(int gi = wave; gi < kn; gi += C::NW)
+            {
+                const lfi_float2 off = {c_offsets[2 * (k0 + gi)], c_offsets[2 * (k0 + gi) + 1]};
+                const uint32_t *plane = grid32 + (size_t)(k0 + gi) * plane_px;
+                const int sx0 = clampi(warp_float(x0 + lane, f0, off.x), 0, W - 1);
+                const int sy0 = clampi(warp_float(y, f0, off.y), 0, H - 1);
+                const int sx1 = clampi(warp_float(x0 + 64 + lane, f1, off.x), 0, W - 1);
+                const int sy1 = clampi(warp_float(y, f1, off.y), 0, H - 1);
+                dma4(plane + (size_t)sy0 * W + sx0, px_addr + uint32_t(gi) * 512u);
+                dma4(plane + (size_t)sy1 * W + sx1, px_addr + uint32_t(gi) * 512u + 256u);
+            }
+        }
+    };
+
+    // ---- unit sequence of this workgroup: tiles j, j+G, j+2G … ; for each: passes × chunks --------------------------------------
+    const int G = gridDim.x;
+    int t = int(xcd_contiguous(blockIdx.x, gridDim.x));
+    if(t >= n_tiles)
+        return;
+    int pass = 0, k0 = 0, buf = 0;
+    bool prev_full_stores = false;
+    issue(t, 0, 0, 0);
+
+    f32x16 acc[MT][3];
+#pragma unroll
+    for(int m = 0; m < MT; m++)
+#pragma unroll
+        for(int c = 0; c < 3; c++)
+#pragma unroll
+            for(int e = 0; e < 16; e++)
+                acc[m][c][e] = 0.0f;
+
+    while(true)
+    {
+        // next unit
+        int nt = t, npass = pass, nk0 = k0 + KC;
+        if(nk0 >= a.k_pad)
+        {
+            nk0 = 0;
+            npass = pass + 1;
+            if(npass >= view_passes)
+            {
+                npass = 0;
+                nt = t + G;
+            }
+        }
+        const bool have_next = nt < n_tiles;
+
+        // (A) this wave's pieces of the current unit have landed; the previous epilogue's stores may still be in flight
+        if(prev_full_stores)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::STORES) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // everybody's pieces have landed; everybody is done with the other buffer
+        asm volatile("" ::: "memory");
+        if(have_next)
+            issue(nt, npass, nk0, buf ^ 1);
+
+        // ---- compute the current unit from buffer `buf` ----------------------------------------------------------------------------
+        const int kc = min(KC, a.k_pad - k0);
+        const uint32_t *px_buf = lds + buf * C::BUF_DW;
+        const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(px_buf + C::PX_DW);
+        const uint32_t *col = px_buf + wave * 32 + r + 8 * h * TPX; // this lane's pixel column, first image of its k-half
+#pragma unroll
+        for(int ks = 0; ks < KS; ks++)
+        {
+            if(16 * ks < kc)
+            {
+                half8 wfrag[MT];
+#pragma unroll
+                for(int m = 0; m < MT; m++)
+                    wfrag[m] = __builtin_bit_cast(half8, w_buf[(2 * ks + h) * VPP + m * 32 + r]);
+                uint32_t px[8];
+#pragma unroll
+                for(int j = 0; j < 8; j++)
+                    px[j] = col[(16 * ks + j) * TPX];
+                u32x4 bc[3];
+#pragma unroll
+                for(int q = 0; q < 4; q++)
+                {
+                    bc[0][q] = pack_subnormal_pair<0>(px[2 * q], px[2 * q + 1]);
+                    bc[1][q] = pack_subnormal_pair<1>(px[2 * q], px[2 * q + 1]);
+                    bc[2][q] = pack_subnormal_pair<2>(px[2 * q], px[2 * q + 1]);
+                }
+#pragma unroll
+                for(int c = 0; c < 3; c++)
+                {
+                    const half8 bfrag = __builtin_bit_cast(half8, bc[c]);
+#pragma unroll
+                    for(int m = 0; m < MT; m++)
+                        acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[m], bfrag, acc[m][c], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- last chunk of the tile: epilogue ----------------------------------------------------------------------------------------
+        prev_full_stores = false;
+        if(k0 + KC >= a.k_pad)
+        {
+            const int y = t / tiles_x;
+            const int x0 = (t - y * tiles_x) * TPX;
+            const int xw = x0 + wave * 32;
+            const int vbase = a.v0 + pass * VPP;
+            const bool full = (x0 + TPX <= W) && (vbase + VPP <= a.v1); // wave-uniform: every store below is issued
+#pragma unroll
+            for(int m = 0; m < MT; m++)
+            {
+                uint32_t rgba[16];
+                quantize_tile_packed(acc[m][0], acc[m][1], acc[m][2], rgba);
+                const int view_m = vbase + m * 32;
+                uint32_t *ubase = reinterpret_cast<uint32_t *>(a.views) + (size_t)view_m * plane_px + (size_t)y * W + xw;
+                const uint32_t lane_off = uint32_t(r) + uint32_t(4 * h) * uint32_t(plane_px);
+#pragma unroll
+                for(int e = 0; e < 16; e++)
+                {
+                    const int vrow = (e & 3) + 8 * (e >> 2); // + 4h in lane_off
+                    uint32_t *out = ubase + (size_t)vrow * plane_px + lane_off;
+                    if(full || (view_m + vrow + 4 * h < a.v1 && xw + r < W))
+                    {
+                        if constexpr(NT_STORE)
+                            __builtin_nontemporal_store(rgba[e], out);
+                        else
+                            *out = rgba[e];
+                    }
+                }
+#pragma unroll
+                for(int c = 0; c < 3; c++)
+#pragma unroll
+                    for(int e = 0; e < 16; e++)
+                        acc[m][c][e] = 0.0f;
+            }
+            prev_full_stores = full;
+        }
+
+        if(!have_next)
+            break;
+        t = nt;
+        pass = npass;
+        k0 = nk0;
+        buf ^= 1;
+    }
+}
+
+} // namespace lfi

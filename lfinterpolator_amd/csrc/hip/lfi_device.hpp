@@ -30,6 +30,7 @@ struct KernelArgs
     const lfi_int2 *__restrict__ focused;   // [Kpad]         integer offsets       (focusedOffsets), zero padded
     const lfi_float2 *__restrict__ offsets; // [Kpad]         float offsets         (offsets), zero padded
     const uint16_t *__restrict__ w16;       // [Vpad][Kpad]   fp16 weights, zero padded (weights, src/interpolator.cu:211)
+    const uint16_t *__restrict__ w16s;      // [Vpad][Kpad]   the same weights × 2^15 (exact) for the packed epilogue; valid iff all in [0,2)
     const float *__restrict__ w32;          // [Vpad][Kpad]   the same weights widened to f32 (exact)
     const float *__restrict__ w32t;         // [Kpad][Vpad]   transposed copy for view-contiguous scalar loads
     const int32_t *__restrict__ focus_ids;  // [n_focus_ids]                        (focusMapIDs)

@@ -13,6 +13,8 @@
 #include "../../../include/lfi.h"
 #include "blend_std.hpp"
 #include "blend_ten.hpp"
+#include "blend_ten_lds.hpp"
+#include "blend_ten_persist.hpp"
 #include "focus_map.hpp"
 #include "lfi_device.hpp"
 
@@ -22,30 +24,22 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct TenVariant
+struct Variant
 {
     const char *name;
-    int pxl, mt;
+    void (*launch)(const lfi_ctx *, const KernelArgs &, bool all_focus);
+    bool packed_epilogue; // needs weights in [0,2) (scaled copy) and cannot report pre-quantisation values
 };
-// first entry = default ("auto")
-constexpr TenVariant kTenVariants[] = {
-    {"direct_p1m2", 1, 2}, {"direct_p2m2", 2, 2}, {"direct_p2m1", 2, 1}, {"direct_p4m1", 4, 1}, {"direct_p1m1", 1, 1},
-};
-struct StdVariant
-{
-    const char *name;
-    int kind; // 0 = valu, 1 = mfma
-    int pxl, mt;
-};
-constexpr StdVariant kStdVariants[] = {
-    {"mfma_p1m2", 1, 1, 2}, {"mfma_p2m2", 1, 2, 2}, {"mfma_p2m1", 1, 2, 1}, {"mfma_p4m1", 1, 4, 1}, {"valu", 0, 1, 0},
-};
+extern const Variant kTenVariants[];
+extern const Variant kStdVariants[];
+extern const int kNumTenVariants, kNumStdVariants;
 
 } // namespace
 
 struct lfi_ctx
 {
     int device = 0;
+    int cu_count = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -63,7 +57,8 @@ struct lfi_ctx
     void *param_blob = nullptr; // one allocation holding all parameter arrays
     lfi_int2 *d_focused = nullptr;
     lfi_float2 *d_offsets = nullptr;
-    uint16_t *d_w16 = nullptr;
+    uint16_t *d_w16 = nullptr, *d_w16s = nullptr;
+    bool weights_scalable = false; // every weight finite and in [0, 2): the ×2^15 copy is exact and the packed epilogue valid
     float *d_w32 = nullptr, *d_w32t = nullptr;
     int32_t *d_ids = nullptr;
     float focus = 0, range = 0;
@@ -114,6 +109,7 @@ KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
     a.focused = c->d_focused;
     a.offsets = c->d_offsets;
     a.w16 = c->d_w16;
+    a.w16s = c->d_w16s;
     a.w32 = c->d_w32;
     a.w32t = c->d_w32t;
     a.focus_ids = c->d_ids;
@@ -145,94 +141,114 @@ dim3 pixel_grid(const lfi_ctx *c)
     return dim3((c->width + 63) / 64, (c->height + 3) / 4, 1);
 }
 
+hipStream_t stream_of(const lfi_ctx *c);
+uint32_t flags_of(const lfi_ctx *c);
+dim3 pixel_grid_of(const lfi_ctx *c);
+int cu_count_of(const lfi_ctx *c);
+
 template <int PXL, int MT>
-void launch_ten(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+void launch_ten_direct(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
-    const int tiles_x = (c->width + 32 * PXL - 1) / (32 * PXL);
-    const int n_tiles = tiles_x * c->height;
+    const int tiles_x = (a.width + 32 * PXL - 1) / (32 * PXL);
+    const int n_tiles = tiles_x * a.height;
     const int passes = (a.v1 - a.v0 + 32 * MT - 1) / (32 * MT);
     const int vpw = passes >= 4 ? 4 : (passes >= 2 ? 2 : 1);
     const int tiles_per_wg = 4 / vpw;
     const dim3 grid((n_tiles + tiles_per_wg - 1) / tiles_per_wg), block(256);
-    const bool per_batch = (c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) != 0;
+    hipStream_t st = stream_of(c);
     if constexpr(PXL == 1 && MT == 2)
     {
-        if(per_batch)
+        if(flags_of(c) & LFI_FLAG_TEN_ROUND_PER_BATCH)
         {
             if(all_focus)
-                hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, true, true>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+                hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, true, true>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
             else
-                hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false, true>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+                hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false, true>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
             return;
         }
     }
     if(all_focus)
-        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, true, false>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, true, false>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
     else
-        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false, false>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false, false>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
+}
+
+template <int NT, int MT, int WPX, int WV, int KC, int WPE>
+void launch_ten_lds(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    constexpr int TPX = WPX * NT * 32, VPP = WV * MT * 32;
+    const int tiles_x = (a.width + TPX - 1) / TPX;
+    const int n_tiles = tiles_x * a.height;
+    const int passes = (a.v1 - a.v0 + VPP - 1) / VPP;
+    const dim3 grid(n_tiles), block(WPX * WV * 64);
+    if(all_focus)
+        hipLaunchKernelGGL((lfi::blend_ten_lds<NT, MT, WPX, WV, KC, WPE, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
+    else
+        hipLaunchKernelGGL((lfi::blend_ten_lds<NT, MT, WPX, WV, KC, WPE, false>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
+}
+
+template <int MT, bool NT_STORE>
+void launch_ten_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    constexpr int TPX = 128, VPP = MT * 32;
+    const int tiles_x = (a.width + TPX - 1) / TPX;
+    const int n_tiles = tiles_x * a.height;
+    const int passes = (a.v1 - a.v0 + VPP - 1) / VPP;
+    // persistent: two workgroups per CU (2 x 80 KB of LDS), each walks tiles j, j+G, j+2G ...
+    const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    if(all_focus)
+        hipLaunchKernelGGL((lfi::blend_ten_persist<MT, true, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
+    else
+        hipLaunchKernelGGL((lfi::blend_ten_persist<MT, false, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
 }
 
 template <int PXL, int MT>
 void launch_std_mfma(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
-    const int tiles_x = (c->width + 32 * PXL - 1) / (32 * PXL);
-    const int n_tiles = tiles_x * c->height;
+    const int tiles_x = (a.width + 32 * PXL - 1) / (32 * PXL);
+    const int n_tiles = tiles_x * a.height;
     const int passes = (a.v1 - a.v0 + 32 * MT - 1) / (32 * MT);
     const int vpw = passes >= 4 ? 4 : (passes >= 2 ? 2 : 1);
     const int tiles_per_wg = 4 / vpw;
     const dim3 grid((n_tiles + tiles_per_wg - 1) / tiles_per_wg), block(256);
     if(all_focus)
-        hipLaunchKernelGGL((lfi::blend_std_mfma<PXL, MT, true>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+        hipLaunchKernelGGL((lfi::blend_std_mfma<PXL, MT, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, vpw);
     else
-        hipLaunchKernelGGL((lfi::blend_std_mfma<PXL, MT, false>), grid, block, 0, c->stream, a, tiles_x, n_tiles, passes, vpw);
+        hipLaunchKernelGGL((lfi::blend_std_mfma<PXL, MT, false>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, vpw);
 }
 
-int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
+void launch_std_valu(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
-    const bool af = all_focus != 0;
-    if(method == LFI_METHOD_TEN_WM)
-    {
-        int variant = c->ten_variant;
-        // the per-batch rounding debug mode exists for the default variant only
-        if(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH)
-            variant = 0;
-        const TenVariant &v = kTenVariants[variant];
-        if(v.pxl == 1 && v.mt == 2)
-            launch_ten<1, 2>(c, a, af);
-        else if(v.pxl == 2 && v.mt == 2)
-            launch_ten<2, 2>(c, a, af);
-        else if(v.pxl == 2 && v.mt == 1)
-            launch_ten<2, 1>(c, a, af);
-        else if(v.pxl == 4 && v.mt == 1)
-            launch_ten<4, 1>(c, a, af);
-        else
-            launch_ten<1, 1>(c, a, af);
-    }
-    else if(method == LFI_METHOD_STD)
-    {
-        const StdVariant &v = kStdVariants[c->std_variant];
-        if(v.kind == 0)
-        {
-            if(af)
-                hipLaunchKernelGGL((lfi::blend_std_valu<true, 16>), pixel_grid(c), dim3(256), 0, c->stream, a);
-            else
-                hipLaunchKernelGGL((lfi::blend_std_valu<false, 16>), pixel_grid(c), dim3(256), 0, c->stream, a);
-        }
-        else if(v.pxl == 1 && v.mt == 2)
-            launch_std_mfma<1, 2>(c, a, af);
-        else if(v.pxl == 2 && v.mt == 2)
-            launch_std_mfma<2, 2>(c, a, af);
-        else if(v.pxl == 2 && v.mt == 1)
-            launch_std_mfma<2, 1>(c, a, af);
-        else
-            launch_std_mfma<4, 1>(c, a, af);
-    }
+    if(all_focus)
+        hipLaunchKernelGGL((lfi::blend_std_valu<true, 16>), pixel_grid_of(c), dim3(256), 0, stream_of(c), a);
     else
-        // the reference throws here (src/interpolator.cu:289-290)
-        return fail(c, LFI_EINVAL, "The specified interpolation method does not exist!");
-    LFI_HIP(c, hipGetLastError());
-    return LFI_OK;
+        hipLaunchKernelGGL((lfi::blend_std_valu<false, 16>), pixel_grid_of(c), dim3(256), 0, stream_of(c), a);
 }
+
+// first entry = default ("auto")
+const Variant kTenVariants[] = {
+    {"persist_m2_nt", launch_ten_persist<2, true>, true},
+    {"persist_m2", launch_ten_persist<2, false>, true},
+    {"direct_p1m2", launch_ten_direct<1, 2>, false},
+    {"persist_m1", launch_ten_persist<1, false>, true},
+    {"lds_n1m2_w3", launch_ten_lds<1, 2, 4, 1, 64, 3>, true},
+    {"lds_n1m1_w4", launch_ten_lds<1, 1, 4, 1, 64, 4>, true},
+    {"lds_n2m1_w3", launch_ten_lds<2, 1, 2, 2, 64, 3>, true},
+    {"lds_n1m1x8_w2", launch_ten_lds<1, 1, 4, 2, 64, 2>, true},
+    {"direct_p2m2", launch_ten_direct<2, 2>, false},
+    {"direct_p2m1", launch_ten_direct<2, 1>, false},
+    {"direct_p4m1", launch_ten_direct<4, 1>, false},
+    {"direct_p1m1", launch_ten_direct<1, 1>, false},
+};
+const Variant kStdVariants[] = {
+    {"mfma_p1m2", launch_std_mfma<1, 2>, false}, {"mfma_p2m2", launch_std_mfma<2, 2>, false}, {"mfma_p2m1", launch_std_mfma<2, 1>, false},
+    {"mfma_p4m1", launch_std_mfma<4, 1>, false}, {"valu", launch_std_valu, false},
+};
+const int kNumTenVariants = sizeof(kTenVariants) / sizeof(kTenVariants[0]);
+const int kNumStdVariants = sizeof(kStdVariants) / sizeof(kStdVariants[0]);
+constexpr int kGenericTenVariant = 2; // direct_p1m2: plain fp32 epilogue, any weights, pre-quantisation dump, per-batch rounding
+
+int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a);
 
 int check_render_args(lfi_ctx *c, int method, int v0, int v1)
 {
@@ -246,6 +262,31 @@ int check_render_args(lfi_ctx *c, int method, int v0, int v1)
         return fail(c, LFI_EINVAL, "The specified interpolation method does not exist!");
     if(v0 < 0 || v1 > c->views_n || v0 >= v1)
         return fail(c, LFI_EINVAL, "view range [v0, v1) outside [0, views)");
+    return LFI_OK;
+}
+
+hipStream_t stream_of(const lfi_ctx *c) { return c->stream; }
+uint32_t flags_of(const lfi_ctx *c) { return c->flags; }
+dim3 pixel_grid_of(const lfi_ctx *c) { return pixel_grid(c); }
+int cu_count_of(const lfi_ctx *c) { return c->cu_count; }
+
+int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
+{
+    if(method == LFI_METHOD_TEN_WM)
+    {
+        // the generic kernel (direct_p1m2) serves what the packed-epilogue kernels cannot: the per-batch rounding debug
+        // mode, pre-quantisation dumps, and weights outside [0, 2)
+        int variant = c->ten_variant;
+        if((c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) || (kTenVariants[variant].packed_epilogue && (!c->weights_scalable || a.prequant)))
+            variant = kGenericTenVariant;
+        kTenVariants[variant].launch(c, a, all_focus != 0);
+    }
+    else if(method == LFI_METHOD_STD)
+        kStdVariants[c->std_variant].launch(c, a, all_focus != 0);
+    else
+        // the reference throws here (src/interpolator.cu:289-290)
+        return fail(c, LFI_EINVAL, "The specified interpolation method does not exist!");
+    LFI_HIP(c, hipGetLastError());
     return LFI_OK;
 }
 
@@ -329,6 +370,7 @@ int lfi_create(int device, lfi_ctx **out_ctx)
                     std::string("device is ") + prop.gcnArchName + "; the kernels in this library are built for gfx950 only");
     lfi_ctx *c = new lfi_ctx();
     c->device = device;
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if(hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
     {
@@ -375,7 +417,7 @@ int lfi_set_grid(lfi_ctx *ctx, int cols, int rows, int width, int height)
         return fail(ctx, LFI_EINVAL, "grid dimensions must be positive");
     if((long)cols * rows > LFI_MAX_IMAGES)
         return fail(ctx, LFI_EINVAL, "more than LFI_MAX_IMAGES (256) grid images");
-    if((size_t)width * height > (size_t)1 << 28)
+    if((size_t)width * height > (size_t)1 << 26)
         return fail(ctx, LFI_EINVAL, "image too large");
     if(int rc = bind(ctx))
         return rc;
@@ -487,7 +529,8 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     const size_t off_focused = 0;
     const size_t off_offsets = off_focused + sizeof(lfi_int2) * k_pad;
     const size_t off_w16 = off_offsets + sizeof(lfi_float2) * k_pad;
-    const size_t off_w32 = (off_w16 + sizeof(uint16_t) * (size_t)v_pad * k_pad + 15) / 16 * 16;
+    const size_t off_w16s = (off_w16 + sizeof(uint16_t) * (size_t)v_pad * k_pad + 15) / 16 * 16;
+    const size_t off_w32 = (off_w16s + sizeof(uint16_t) * (size_t)v_pad * k_pad + 15) / 16 * 16;
     const size_t off_w32t = off_w32 + sizeof(float) * (size_t)v_pad * k_pad;
     const size_t off_ids = off_w32t + sizeof(float) * (size_t)v_pad * k_pad;
     const size_t total = off_ids + sizeof(int32_t) * LFI_MAX_FOCUS_IDS;
@@ -495,6 +538,8 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     std::memcpy(blob.data() + off_focused, p->focused_offsets, sizeof(lfi_int2) * n);
     std::memcpy(blob.data() + off_offsets, p->offsets, sizeof(lfi_float2) * n);
     uint16_t *w16 = reinterpret_cast<uint16_t *>(blob.data() + off_w16);
+    uint16_t *w16s = reinterpret_cast<uint16_t *>(blob.data() + off_w16s);
+    bool scalable = true;
     float *w32 = reinterpret_cast<float *>(blob.data() + off_w32);
     float *w32t = reinterpret_cast<float *>(blob.data() + off_w32t);
     for(int v = 0; v < V; v++)
@@ -503,6 +548,11 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
             const uint16_t h = p->weights_fp16[(size_t)v * n + g];
             const float f = static_cast<float>(__builtin_bit_cast(_Float16, h)); // half → float is exact
             w16[(size_t)v * k_pad + g] = h;
+            // × 2^15 is exact in fp16 for every finite weight in [0, 2) (subnormals become normal, 1.999 → 65472)
+            if(!(f >= 0.0f && f < 2.0f))
+                scalable = false;
+            else
+                w16s[(size_t)v * k_pad + g] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(f * 32768.0f));
             w32[(size_t)v * k_pad + g] = f;
             w32t[(size_t)g * v_pad + v] = f;
         }
@@ -516,6 +566,8 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     ctx->d_focused = reinterpret_cast<lfi_int2 *>(base + off_focused);
     ctx->d_offsets = reinterpret_cast<lfi_float2 *>(base + off_offsets);
     ctx->d_w16 = reinterpret_cast<uint16_t *>(base + off_w16);
+    ctx->d_w16s = reinterpret_cast<uint16_t *>(base + off_w16s);
+    ctx->weights_scalable = scalable;
     ctx->d_w32 = reinterpret_cast<float *>(base + off_w32);
     ctx->d_w32t = reinterpret_cast<float *>(base + off_w32t);
     ctx->d_ids = reinterpret_cast<int32_t *>(base + off_ids);
@@ -733,10 +785,10 @@ const char *lfi_list_variants(int method)
     static std::string ten, std_;
     if(ten.empty())
     {
-        for(const auto &v : kTenVariants)
-            ten += std::string(ten.empty() ? "" : ",") + v.name;
-        for(const auto &v : kStdVariants)
-            std_ += std::string(std_.empty() ? "" : ",") + v.name;
+        for(int i = 0; i < kNumTenVariants; i++)
+            ten += std::string(ten.empty() ? "" : ",") + kTenVariants[i].name;
+        for(int i = 0; i < kNumStdVariants; i++)
+            std_ += std::string(std_.empty() ? "" : ",") + kStdVariants[i].name;
     }
     if(method == LFI_METHOD_TEN_WM)
         return ten.c_str();
@@ -757,7 +809,7 @@ int lfi_set_variant(lfi_ctx *ctx, int method, const char *name)
             ctx->ten_variant = 0;
             return LFI_OK;
         }
-        for(size_t i = 0; i < sizeof(kTenVariants) / sizeof(kTenVariants[0]); i++)
+        for(int i = 0; i < kNumTenVariants; i++)
             if(std::strcmp(name, kTenVariants[i].name) == 0)
             {
                 ctx->ten_variant = int(i);
@@ -771,7 +823,7 @@ int lfi_set_variant(lfi_ctx *ctx, int method, const char *name)
             ctx->std_variant = 0;
             return LFI_OK;
         }
-        for(size_t i = 0; i < sizeof(kStdVariants) / sizeof(kStdVariants[0]); i++)
+        for(int i = 0; i < kNumStdVariants; i++)
             if(std::strcmp(name, kStdVariants[i].name) == 0)
             {
                 ctx->std_variant = int(i);

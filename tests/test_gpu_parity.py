@@ -254,3 +254,41 @@ def test_error_behaviour(gpu):
     with pytest.raises(gpu.LfiError):
         ctx.set_grid(17, 17, 8, 8)  # more than 256 images
     ctx.close()
+
+
+def test_weights_outside_unit_range_use_the_generic_kernel(gpu, oracle_c):
+    """The packed epilogue needs weights in [0, 2); anything else (negative, ≥ 2: not produced by the reference's
+    generator but legal through the C-ABI) must fall back to the generic kernel and still saturate like __half2uchar_rz."""
+    cols = rows = 4
+    W, H, V = 96, 10, 8
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.2, 0.0, 3.0, 1.0, V)
+    w = hp.weights.view(np.float16).astype(np.float32)
+    w[0] *= 3.0           # sums > 255 → saturate at 255
+    w[1] = -w[1]          # negative sums → 0
+    w[2, 0] = 2.5         # a single weight ≥ 2
+    w[3] *= 0.25
+    hp.weights = w.astype(np.float16).view(np.uint16)
+    lf = oracle_c.synthetic_lf(16, W, H, SEED)
+    ctx = _ctx(gpu, cols, rows, W, H, hp)
+    m16 = oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights)
+    assert (m16[0] == 255)[..., :3].mean() > 0.5 and (m16[1][..., :3] == 0).all()
+    for variant in ctx.list_variants("TEN_WM"):
+        ctx.set_variant("TEN_WM", variant)
+        ctx.render("TEN_WM")
+        ctx.sync()
+        assert np.abs(ctx.download_views().astype(int) - m16.astype(int)).max() <= TEN_TOL_LSB, variant
+    # in-range but large weights (1 ≤ w < 2) stay on the packed path and saturate there
+    hp2 = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.2, 0.0, 3.0, 1.0, V)
+    w2 = hp2.weights.view(np.float16).astype(np.float32)
+    w2 = w2 * (1.9 / w2.max())
+    assert w2.max() < 2.0 and w2.max() > 1.0
+    hp2.weights = w2.astype(np.float16).view(np.uint16)
+    ctx.set_params(hp2)
+    m16b = oracle_c.blend_ten(lf, hp2.focused_offsets, hp2.offsets, hp2.weights)
+    assert (m16b == 255).mean() > 0.3
+    for variant in ctx.list_variants("TEN_WM"):
+        ctx.set_variant("TEN_WM", variant)
+        ctx.render("TEN_WM")
+        ctx.sync()
+        assert np.abs(ctx.download_views().astype(int) - m16b.astype(int)).max() <= TEN_TOL_LSB, variant
+    ctx.close()
