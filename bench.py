@@ -104,14 +104,13 @@ def main() -> int:
     if rank == 0:
         ctx.fill_synthetic(SEED)
         ctx.sync()
-    if world > 1:
-        dist.broadcast(grid, src=0)  # the one collective of the job: 531 MB over xGMI, outside the timed region
-        torch.cuda.synchronize()
+    L.broadcast_grid(grid, src=0)    # the one collective of the job: 531 MB over xGMI (RCCL), outside the timed region
+    torch.cuda.synchronize()
 
     # host parameters for the whole trajectory; each rank keeps its own rows of the weight matrix
     total_views = VIEWS_PER_GPU * world
-    hp_all = L.build_params(COLS, ROWS, WIDTH, HEIGHT, TRAJECTORY, FOCUS, 0.0, EFFECT, ASPECT, total_views)
-    hp = hp_all.rows(rank * VIEWS_PER_GPU, (rank + 1) * VIEWS_PER_GPU)
+    hp, v0, v1 = L.rank_params(COLS, ROWS, WIDTH, HEIGHT, TRAJECTORY, FOCUS, 0.0, EFFECT, ASPECT, total_views, world, rank)
+    assert v1 - v0 == VIEWS_PER_GPU
     ctx.set_params(hp)
     views = torch.empty((VIEWS_PER_GPU, HEIGHT, WIDTH, 4), dtype=torch.uint8, device=dev)
     ctx.attach_views(views.data_ptr(), views.numel())

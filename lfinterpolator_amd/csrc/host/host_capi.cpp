@@ -47,3 +47,82 @@ float lfi_host_half_to_float(uint16_t h)
 }
 
 } // extern "C"
+
+// ---- image I/O and the loader, for the tests of the steps either side of the hot path ----------------------------------
+#include "image_io.h"
+#include "lfLoader.h"
+
+extern "C" {
+
+// decode a PNG / PPM into caller memory (RGBA8); call with rgba == NULL to query the size
+int lfi_host_load_image(const char *path, int *width, int *height, uint8_t *rgba, char *err, size_t err_len)
+{
+    try
+    {
+        lfi::Image img = lfi::loadImage(path);
+        *width = img.width;
+        *height = img.height;
+        if(rgba)
+            std::memcpy(rgba, img.pixels.data(), img.pixels.size());
+        return 0;
+    }
+    catch(const std::exception &e)
+    {
+        if(err && err_len)
+        {
+            std::strncpy(err, e.what(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+        return -1;
+    }
+}
+
+int lfi_host_write_png(const char *path, int width, int height, int channels, const uint8_t *data, char *err, size_t err_len)
+{
+    try
+    {
+        lfi::writePng(path, width, height, channels, data, static_cast<size_t>(width) * channels);
+        return 0;
+    }
+    catch(const std::exception &e)
+    {
+        if(err && err_len)
+        {
+            std::strncpy(err, e.what(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+        return -1;
+    }
+}
+
+// LfLoader::loadData on a directory: returns cols/rows/resolution and (if planes != NULL) the images in g = col*rows+row order
+int lfi_host_load_grid(const char *path, int *cols, int *rows, int *width, int *height, uint8_t *planes, char *err, size_t err_len)
+{
+    try
+    {
+        LfLoader loader;
+        loader.loadData(path);
+        const lfi::IVec2 cr = loader.getColsRows();
+        const lfi::IVec3 res = loader.imageResolution();
+        *cols = cr.x;
+        *rows = cr.y;
+        *width = res.x;
+        *height = res.y;
+        if(planes)
+            for(int col = 0; col < cr.x; col++)
+                for(int row = 0; row < cr.y; row++)
+                    std::memcpy(planes + loader.imageSize() * (static_cast<size_t>(col) * cr.y + row), loader.image({col, row}).data(), loader.imageSize());
+        return 0;
+    }
+    catch(const std::exception &e)
+    {
+        if(err && err_len)
+        {
+            std::strncpy(err, e.what(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+        return -1;
+    }
+}
+
+} // extern "C"

@@ -27,6 +27,12 @@ def load_host_library() -> C.CDLL:
         lib.lfi_host_float_to_half.argtypes = [C.c_float]
         lib.lfi_host_half_to_float.restype = C.c_float
         lib.lfi_host_half_to_float.argtypes = [C.c_uint16]
+        lib.lfi_host_load_image.restype = C.c_int
+        lib.lfi_host_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_char_p, C.c_size_t]
+        lib.lfi_host_write_png.restype = C.c_int
+        lib.lfi_host_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
+        lib.lfi_host_load_grid.restype = C.c_int
+        lib.lfi_host_load_grid.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 4 + [C.c_void_p, C.c_char_p, C.c_size_t]
         _lib = lib
     return _lib
 
@@ -66,3 +72,37 @@ def build_params(cols: int, rows: int, width: int, height: int, trajectory: str,
     if rc != 0:
         raise ValueError(err.value.decode())
     return HostParams(foc, off, w, ids[:n_ids.value].copy(), focus, range, np.array([radius[0], radius[1]], np.int32))
+
+
+def _err_call(fn, *args):
+    err = C.create_string_buffer(512)
+    rc = fn(*args, err, len(err))
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+
+
+def load_image(path: str) -> np.ndarray:
+    """csrc/host/image_io.cpp: PNG / PPM → [H][W][4] u8."""
+    lib = load_host_library()
+    w, h = C.c_int(), C.c_int()
+    _err_call(lib.lfi_host_load_image, path.encode(), C.byref(w), C.byref(h), None)
+    out = np.empty((h.value, w.value, 4), dtype=np.uint8)
+    _err_call(lib.lfi_host_load_image, path.encode(), C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def write_png(path: str, image: np.ndarray) -> None:
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w, c = image.shape
+    _err_call(load_host_library().lfi_host_write_png, path.encode(), w, h, c, image.ctypes.data_as(C.c_void_p))
+
+
+def load_grid(path: str):
+    """LfLoader::loadData: returns (cols, rows, [N][H][W][4] u8 with g = col*rows + row)."""
+    lib = load_host_library()
+    cols, rows, w, h = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _err_call(lib.lfi_host_load_grid, path.encode(), C.byref(cols), C.byref(rows), C.byref(w), C.byref(h), None)
+    out = np.empty((cols.value * rows.value, h.value, w.value, 4), dtype=np.uint8)
+    _err_call(lib.lfi_host_load_grid, path.encode(), C.byref(cols), C.byref(rows), C.byref(w), C.byref(h),
+              out.ctypes.data_as(C.c_void_p))
+    return cols.value, rows.value, out

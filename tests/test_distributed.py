@@ -1,0 +1,74 @@
+"""CPU, world_size 2, gloo: the multi-GPU path's logic — view sharding, per-rank weight rows, the single grid broadcast —
+with the oracle standing in for the kernel (tests only).  Real multi-GPU runs are the driver's (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def test_view_range_partition(native):
+    for total, world in [(64, 1), (64, 2), (64, 8), (256, 8), (45, 4), (7, 8), (0, 3)]:
+        ranges = [native.view_range(total, world, r) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == total
+        for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
+            assert a1 == b0 and a0 <= a1
+        sizes = [b - a for a, b in ranges]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        native.view_range(8, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    import lfinterpolator_amd as L
+    from oracle import lfi_oracle_c as oc  # checker standing in for the GPU kernel in this CPU test
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cols = rows = 4
+    W, H, total = 48, 20, 10
+    grid = torch.zeros((cols * rows, H, W, 4), dtype=torch.uint8)
+    if rank == 0:
+        grid.copy_(torch.from_numpy(oc.synthetic_lf(cols * rows, W, H, 0x1F1F)))
+    L.broadcast_grid(grid, src=0)
+    hp, v0, v1 = L.rank_params(cols, rows, W, H, "0,0,1,1", 0.23, 0.0, 3.0, 1.783, total, world, rank)
+    assert hp.weights.shape[0] == v1 - v0
+    local = oc.blend_std(grid.numpy(), hp.focused_offsets, hp.offsets, hp.weights)
+    # MAX over ranks of a per-rank time, as bench.py does
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t[0]) == world
+    dist.barrier()
+    np.save(os.path.join(out_dir, f"views_{rank}.npy"), local)
+    np.save(os.path.join(out_dir, f"range_{rank}.npy"), np.array([v0, v1]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_view_sharding_matches_single_rank(native, oracle_c, tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    cols = rows = 4
+    W, H, total = 48, 20, 10
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, 0x1F1F)
+    hp = native.build_params(cols, rows, W, H, "0,0,1,1", 0.23, 0.0, 3.0, 1.783, total)
+    full = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)
+    covered = 0
+    for r in range(world):
+        v0, v1 = np.load(tmp_path / f"range_{r}.npy")
+        part = np.load(tmp_path / f"views_{r}.npy")
+        assert (part == full[v0:v1]).all()
+        covered += v1 - v0
+    assert covered == total
