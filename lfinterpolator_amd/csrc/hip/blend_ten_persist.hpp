@@ -50,10 +50,9 @@ struct PersistCfg
     static constexpr int TPX = 128;              // pixels per tile: 32 per wave, one per lane column
     static constexpr int KC = 64;                // images per chunk
     static constexpr int VPP = MT * 32;          // views per pass
-    static constexpr int PX_DW = KC * TPX;       // dwords of pixels per buffer (32 KB)
-    static constexpr int W_DW = (KC / 8) * VPP * 4; // dwords of weight fragments per buffer: [k-octet][view] × 16 B
-    static constexpr int BUF_DW = PX_DW + W_DW;
-    static constexpr int STORES = MT * 16;       // epilogue stores per wave on a full tile
+    static constexpr int PX_DW = KC * TPX;       // dwords of pixels per pixel buffer (32 KB)
+    static constexpr int W_DW = (KC / 8) * VPP * 4; // dwords of weight fragments per weight buffer: [k-octet][view] × 16 B
+    static constexpr int LDS_DW = 2 * PX_DW + 2 * W_DW; // two pixel buffers, then two weight buffers
 };
 
 template <int MT, bool ALLFOCUS, bool NT_STORE>
@@ -62,7 +61,7 @@ __global__ void __launch_bounds__(256, 2)
 {
     using C = PersistCfg<MT, ALLFOCUS, NT_STORE>;
     constexpr int TPX = C::TPX, KC = C::KC, VPP = C::VPP, KS = KC / 16;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * C::BUF_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[C::LDS_DW];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -79,13 +78,13 @@ __global__ void __launch_bounds__(256, 2)
     const const_float_ptr c_offsets = (const_float_ptr)(uintptr_t)a.offsets;
 
     // ---- issue the LDS-DMA of one unit (tile t, view pass `pass`, chunk k0) into buffer b ------------------------------------
-    auto issue = [&](int t, int pass, int k0, int b) {
+    auto issue = [&](int t, int pass, int k0, int pb, int wb, bool with_pixels) {
         const int y = t / tiles_x;
         const int x0 = (t - y * tiles_x) * TPX;
         const int kc = min(KC, a.k_pad - k0);
         const int kn = min(kc, a.n_images - k0);
-        const uint32_t px_addr = lds_base + uint32_t(b) * (C::BUF_DW * 4);
-        const uint32_t w_addr = px_addr + C::PX_DW * 4;
+        const uint32_t px_addr = lds_base + uint32_t(pb) * (C::PX_DW * 4);
+        const uint32_t w_addr = lds_base + 2 * C::PX_DW * 4 + uint32_t(wb) * (C::W_DW * 4);
         // weight fragments: one instruction per k-octet o: lane l ← W[v0 + pass*VPP + l][k0 + 8o … +7] (×2^15), 16 bytes,
         // landing at slot o*VPP + l: the A-fragment reads of a k-step are then two contiguous 512-B runs (conflict-free)
         for(int o = wave; 8 * o < kc; o += C::NW)
@@ -96,6 +95,8 @@ __global__ void __launch_bounds__(256, 2)
                 dma16(src, w_addr + uint32_t(o) * (VPP * 16));
             }
         }
+        if(!with_pixels)
+            return; // a later view pass of a single-chunk tile: the pixels are already in LDS
         if constexpr(!ALLFOCUS)
         {
             // pixels: 16 B/lane pieces, two images per instruction (half-wave hh ↔ image 2q+hh, lane column c ↔ pixels 4c…4c+3)
@@ -155,13 +156,16 @@ __global__ void __launch_bounds__(256, 2)
     };
 
     // ---- unit sequence of this workgroup: tiles j, j+G, j+2G … ; for each: passes × chunks --------------------------------------
+    // Pixel buffers alternate per tile when the whole image stack fits one chunk (then every view pass of the tile reuses
+    // them) and per unit otherwise; weight buffers alternate per unit.
     const int G = gridDim.x;
+    const bool single_chunk = a.k_pad <= KC;
     int t = int(xcd_contiguous(blockIdx.x, gridDim.x));
     if(t >= n_tiles)
         return;
-    int pass = 0, k0 = 0, buf = 0;
-    bool prev_full_stores = false;
-    issue(t, 0, 0, 0);
+    int pass = 0, k0 = 0, pbuf = 0, wbuf = 0;
+    int prev_stores = 0; // store instructions this wave issued in the previous epilogue (they are the youngest VMEM ops)
+    issue(t, 0, 0, 0, 0, true);
 
     f32x16 acc[MT][3];
 #pragma unroll
@@ -187,21 +191,31 @@ __global__ void __launch_bounds__(256, 2)
             }
         }
         const bool have_next = nt < n_tiles;
+        const bool next_needs_pixels = !single_chunk || nt != t;
+        const int npbuf = next_needs_pixels ? (pbuf ^ 1) : pbuf;
 
-        // (A) this wave's pieces of the current unit have landed; the previous epilogue's stores may still be in flight
-        if(prev_full_stores)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::STORES) : "memory");
+        // (A) this wave's pieces of the current unit have landed; the previous epilogue's stores may still be in flight.
+        // vmcnt retires in order and the stores are the youngest operations, so waiting for "at most prev_stores outstanding"
+        // covers every DMA piece; the immediate is the largest threshold not above the exact count.
+        if(prev_stores >= 32)
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if(prev_stores >= 24)
+            asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if(prev_stores >= 16)
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if(prev_stores >= 8)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier(); // everybody's pieces have landed; everybody is done with the other buffer
+        __builtin_amdgcn_s_barrier(); // everybody's pieces have landed; everybody is done with the buffers about to be refilled
         asm volatile("" ::: "memory");
         if(have_next)
-            issue(nt, npass, nk0, buf ^ 1);
+            issue(nt, npass, nk0, npbuf, wbuf ^ 1, next_needs_pixels);
 
-        // ---- compute the current unit from buffer `buf` ----------------------------------------------------------------------------
+        // ---- compute the current unit ------------------------------------------------------------------------------------------------
         const int kc = min(KC, a.k_pad - k0);
-        const uint32_t *px_buf = lds + buf * C::BUF_DW;
-        const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(px_buf + C::PX_DW);
+        const uint32_t *px_buf = lds + pbuf * C::PX_DW;
+        const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(lds + 2 * C::PX_DW + wbuf * C::W_DW);
         const uint32_t *col = px_buf + wave * 32 + r + 8 * h * TPX; // this lane's pixel column, first image of its k-half
 #pragma unroll
         for(int ks = 0; ks < KS; ks++)
@@ -236,33 +250,59 @@ __global__ void __launch_bounds__(256, 2)
         }
 
         // ---- last chunk of the tile: epilogue ----------------------------------------------------------------------------------------
-        prev_full_stores = false;
+        prev_stores = 0;
         if(k0 + KC >= a.k_pad)
         {
             const int y = t / tiles_x;
             const int x0 = (t - y * tiles_x) * TPX;
             const int xw = x0 + wave * 32;
             const int vbase = a.v0 + pass * VPP;
-            const bool full = (x0 + TPX <= W) && (vbase + VPP <= a.v1); // wave-uniform: every store below is issued
+            int n_st = 0; // exact count of store instructions issued below (every branch around a store is wave-uniform)
 #pragma unroll
             for(int m = 0; m < MT; m++)
             {
-                uint32_t rgba[16];
-                quantize_tile_packed(acc[m][0], acc[m][1], acc[m][2], rgba);
                 const int view_m = vbase + m * 32;
-                uint32_t *ubase = reinterpret_cast<uint32_t *>(a.views) + (size_t)view_m * plane_px + (size_t)y * W + xw;
-                const uint32_t lane_off = uint32_t(r) + uint32_t(4 * h) * uint32_t(plane_px);
-#pragma unroll
-                for(int e = 0; e < 16; e++)
+                const int nvalid = min(a.v1 - view_m, 32); // views of this M-tile inside the launch's range
+                if(nvalid > 0 && xw < W)
                 {
-                    const int vrow = (e & 3) + 8 * (e >> 2); // + 4h in lane_off
-                    uint32_t *out = ubase + (size_t)vrow * plane_px + lane_off;
-                    if(full || (view_m + vrow + 4 * h < a.v1 && xw + r < W))
+                    uint32_t rgba[16];
+                    quantize_tile_packed(acc[m][0], acc[m][1], acc[m][2], rgba);
+                    uint32_t *ubase = reinterpret_cast<uint32_t *>(a.views) + (size_t)view_m * plane_px + (size_t)y * W + xw;
+                    const uint32_t lane_off = uint32_t(r) + uint32_t(4 * h) * uint32_t(plane_px);
+                    if(nvalid == 32 && xw + 32 <= W)
                     {
-                        if constexpr(NT_STORE)
-                            __builtin_nontemporal_store(rgba[e], out);
-                        else
-                            *out = rgba[e];
+                        // full M-tile, full run: 16 unpredicated stores
+                        n_st += 16;
+#pragma unroll
+                        for(int e = 0; e < 16; e++)
+                        {
+                            uint32_t *out = ubase + (size_t)((e & 3) + 8 * (e >> 2)) * plane_px + lane_off;
+                            if constexpr(NT_STORE)
+                                __builtin_nontemporal_store(rgba[e], out);
+                            else
+                                *out = rgba[e];
+                        }
+                    }
+                    else
+                    {
+                        const bool lane_x_ok = xw + r < W;
+#pragma unroll
+                        for(int e = 0; e < 16; e++)
+                        {
+                            const int vrow = (e & 3) + 8 * (e >> 2); // + 4h in lane_off
+                            if(vrow < nvalid) // wave-uniform; lane (r = 0, h = 0) is then always active, so the store is issued
+                            {
+                                n_st++;
+                                uint32_t *out = ubase + (size_t)vrow * plane_px + lane_off;
+                                if(lane_x_ok && vrow + 4 * h < nvalid)
+                                {
+                                    if constexpr(NT_STORE)
+                                        __builtin_nontemporal_store(rgba[e], out);
+                                    else
+                                        *out = rgba[e];
+                                }
+                            }
+                        }
                     }
                 }
 #pragma unroll
@@ -271,7 +311,7 @@ __global__ void __launch_bounds__(256, 2)
                     for(int e = 0; e < 16; e++)
                         acc[m][c][e] = 0.0f;
             }
-            prev_full_stores = full;
+            prev_stores = n_st;
         }
 
         if(!have_next)
@@ -279,7 +319,8 @@ __global__ void __launch_bounds__(256, 2)
         t = nt;
         pass = npass;
         k0 = nk0;
-        buf ^= 1;
+        pbuf = npbuf;
+        wbuf ^= 1;
     }
 }
 
