@@ -1,4 +1,4 @@
-// blend_ten_persist.hpp — TEN_WM as a persistent, double-buffered LDS-DMA pipeline (the production kernel).
+// blend_ten_persist.hpp — TEN_WM (and STD) as a persistent, double-buffered LDS-DMA pipeline (the production kernels).
 //
 // Measurements that shaped it (profiles/r01_notes.md): the memory system sustains this access pattern (64 shifted input
 // planes gathered, 64 output planes scattered) at ≈5.4–5.8 TB/s with trivial compute; a kernel that does
@@ -43,7 +43,23 @@ __device__ __forceinline__ void dma4(const void *gptr, uint32_t lds_addr)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
 }
 
-template <int MT, bool ALLFOCUS, bool NT_STORE>
+// STD quantisation (uch4, reference src/kernels.cu:301-310): (unsigned char)__float2int_rn(sum), alpha 255.
+// sum + 2^23 rounds to an integer with the default round-to-nearest-even and leaves it in the low mantissa bits, so the
+// low byte IS the reference's result — including its two's-complement wrap for sums outside 0..255 — for |sum| < 2^22.
+__device__ __forceinline__ void quantize_tile_rn(const f32x16 &cr, const f32x16 &cg, const f32x16 &cb, uint32_t (&rgba)[16])
+{
+#pragma unroll
+    for(int e = 0; e < 16; e++)
+    {
+        const uint32_t tr = __builtin_bit_cast(uint32_t, cr[e] + 8388608.0f);
+        const uint32_t tg = __builtin_bit_cast(uint32_t, cg[e] + 8388608.0f);
+        const uint32_t tb = __builtin_bit_cast(uint32_t, cb[e] + 8388608.0f);
+        const uint32_t rg = __builtin_amdgcn_perm(tg, tr, 0x0c0c0400u); // [R, G, 0, 0]
+        rgba[e] = __builtin_amdgcn_perm(tb, rg, 0x0d040100u);           // [R, G, B, 0xff]
+    }
+}
+
+template <int MT>
 struct PersistCfg
 {
     static constexpr int NW = 4;                 // waves per workgroup, side by side along the row
@@ -55,11 +71,13 @@ struct PersistCfg
     static constexpr int LDS_DW = 2 * PX_DW + 2 * W_DW; // two pixel buffers, then two weight buffers
 };
 
-template <int MT, bool ALLFOCUS, bool NT_STORE>
+// STD = false: TEN_WM (fp16 MFMA, packed truncating epilogue, weights ×2^15);  STD = true: the exact-fp32 path of
+// Kernels::Standard::process (reference src/kernels.cu:289-343) on v_mfma_f32_32x32x2_f32 — see blend_std.hpp — in the same pipeline.
+template <bool STD, int MT, bool ALLFOCUS, bool NT_STORE>
 __global__ void __launch_bounds__(256, 2)
-    blend_ten_persist(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes)
+    blend_persist(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes)
 {
-    using C = PersistCfg<MT, ALLFOCUS, NT_STORE>;
+    using C = PersistCfg<MT>;
     constexpr int TPX = C::TPX, KC = C::KC, VPP = C::VPP, KS = KC / 16;
     __shared__ __attribute__((aligned(16))) uint32_t lds[C::LDS_DW];
 
@@ -91,7 +109,7 @@ __global__ void __launch_bounds__(256, 2)
         {
             if(lane < VPP)
             {
-                const uint16_t *src = a.w16s + (size_t)(a.v0 + pass * VPP + lane) * a.k_pad + k0 + 8 * o;
+                const uint16_t *src = (STD ? a.w16 : a.w16s) + (size_t)(a.v0 + pass * VPP + lane) * a.k_pad + k0 + 8 * o;
                 dma16(src, w_addr + uint32_t(o) * (VPP * 16));
             }
         }
@@ -216,35 +234,85 @@ __global__ void __launch_bounds__(256, 2)
         const int kc = min(KC, a.k_pad - k0);
         const uint32_t *px_buf = lds + pbuf * C::PX_DW;
         const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(lds + 2 * C::PX_DW + wbuf * C::W_DW);
-        const uint32_t *col = px_buf + wave * 32 + r + 8 * h * TPX; // this lane's pixel column, first image of its k-half
-#pragma unroll
-        for(int ks = 0; ks < KS; ks++)
+        if constexpr(!STD)
         {
-            if(16 * ks < kc)
+            const uint32_t *col = px_buf + wave * 32 + r + 8 * h * TPX; // this lane's pixel column, first image of its k-half
+#pragma unroll
+            for(int ks = 0; ks < KS; ks++)
             {
-                half8 wfrag[MT];
-#pragma unroll
-                for(int m = 0; m < MT; m++)
-                    wfrag[m] = __builtin_bit_cast(half8, w_buf[(2 * ks + h) * VPP + m * 32 + r]);
-                uint32_t px[8];
-#pragma unroll
-                for(int j = 0; j < 8; j++)
-                    px[j] = col[(16 * ks + j) * TPX];
-                u32x4 bc[3];
-#pragma unroll
-                for(int q = 0; q < 4; q++)
+                if(16 * ks < kc)
                 {
-                    bc[0][q] = pack_subnormal_pair<0>(px[2 * q], px[2 * q + 1]);
-                    bc[1][q] = pack_subnormal_pair<1>(px[2 * q], px[2 * q + 1]);
-                    bc[2][q] = pack_subnormal_pair<2>(px[2 * q], px[2 * q + 1]);
-                }
-#pragma unroll
-                for(int c = 0; c < 3; c++)
-                {
-                    const half8 bfrag = __builtin_bit_cast(half8, bc[c]);
+                    half8 wfrag[MT];
 #pragma unroll
                     for(int m = 0; m < MT; m++)
-                        acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[m], bfrag, acc[m][c], 0, 0, 0);
+                        wfrag[m] = __builtin_bit_cast(half8, w_buf[(2 * ks + h) * VPP + m * 32 + r]);
+                    uint32_t px[8];
+#pragma unroll
+                    for(int j = 0; j < 8; j++)
+                        px[j] = col[(16 * ks + j) * TPX];
+                    u32x4 bc[3];
+#pragma unroll
+                    for(int q = 0; q < 4; q++)
+                    {
+                        bc[0][q] = pack_subnormal_pair<0>(px[2 * q], px[2 * q + 1]);
+                        bc[1][q] = pack_subnormal_pair<1>(px[2 * q], px[2 * q + 1]);
+                        bc[2][q] = pack_subnormal_pair<2>(px[2 * q], px[2 * q + 1]);
+                    }
+#pragma unroll
+                    for(int c = 0; c < 3; c++)
+                    {
+                        const half8 bfrag = __builtin_bit_cast(half8, bc[c]);
+#pragma unroll
+                        for(int m = 0; m < MT; m++)
+                            acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[m], bfrag, acc[m][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        else
+        {
+            // exact fp32: MFMA q of a k-step multiplies image pair (16ks+2q, 16ks+2q+1): k = 0 ↔ lower half-wave, k = 1 ↔ upper,
+            // accumulated in that order = the reference's ascending-g fmaf chain (src/kernels.cu:328-338)
+            const uint32_t *col = px_buf + wave * 32 + r + h * TPX;
+#pragma unroll
+            for(int ks = 0; ks < KS; ks++)
+            {
+                if(16 * ks < kc)
+                {
+                    // pixels of this half-wave's 8 images (2q + h) of the k-step, all requested before the first use
+                    uint32_t px[8];
+#pragma unroll
+                    for(int q = 0; q < 8; q++)
+                        px[q] = col[(16 * ks + 2 * q) * TPX];
+                    // this lane's view row of the fp16 weights for the 16 images of the k-step: two octets of 8 halves;
+                    // image 2q+h sits in bits [16h, 16h+16) of dword q
+                    u32x4 wlo[MT], whi[MT];
+#pragma unroll
+                    for(int m = 0; m < MT; m++)
+                    {
+                        wlo[m] = w_buf[(2 * ks) * VPP + m * 32 + r];
+                        whi[m] = w_buf[(2 * ks + 1) * VPP + m * 32 + r];
+                    }
+                    const uint32_t sh = 16u * uint32_t(h);
+#pragma unroll
+                    for(int q = 0; q < 8; q++)
+                    {
+                        float wq[MT];
+#pragma unroll
+                        for(int m = 0; m < MT; m++)
+                        {
+                            const uint32_t d = q < 4 ? wlo[m][q] : whi[m][q - 4];
+                            wq[m] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(d >> sh))); // exact
+                        }
+                        const uint32_t p = px[q];
+                        const float pc[3] = {static_cast<float>(p & 0xffu), static_cast<float>((p >> 8) & 0xffu),
+                                             static_cast<float>((p >> 16) & 0xffu)};
+#pragma unroll
+                        for(int c = 0; c < 3; c++)
+#pragma unroll
+                            for(int m = 0; m < MT; m++)
+                                acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[m], pc[c], acc[m][c], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -266,7 +334,10 @@ __global__ void __launch_bounds__(256, 2)
                 if(nvalid > 0 && xw < W)
                 {
                     uint32_t rgba[16];
-                    quantize_tile_packed(acc[m][0], acc[m][1], acc[m][2], rgba);
+                    if constexpr(STD)
+                        quantize_tile_rn(acc[m][0], acc[m][1], acc[m][2], rgba);
+                    else
+                        quantize_tile_packed(acc[m][0], acc[m][1], acc[m][2], rgba);
                     uint32_t *ubase = reinterpret_cast<uint32_t *>(a.views) + (size_t)view_m * plane_px + (size_t)y * W + xw;
                     const uint32_t lane_off = uint32_t(r) + uint32_t(4 * h) * uint32_t(plane_px);
                     if(nvalid == 32 && xw + 32 <= W)

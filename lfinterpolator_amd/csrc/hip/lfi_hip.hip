@@ -28,7 +28,8 @@ struct Variant
 {
     const char *name;
     void (*launch)(const lfi_ctx *, const KernelArgs &, bool all_focus);
-    bool packed_epilogue; // needs weights in [0,2) (scaled copy) and cannot report pre-quantisation values
+    bool packed_epilogue; // TEN_WM: needs weights in [0,2) (×2^15 copy)
+    bool prequant = false; // can dump pre-quantisation accumulators (the generic kernels only)
 };
 extern const Variant kTenVariants[];
 extern const Variant kStdVariants[];
@@ -187,8 +188,8 @@ void launch_ten_lds(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
         hipLaunchKernelGGL((lfi::blend_ten_lds<NT, MT, WPX, WV, KC, WPE, false>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
 }
 
-template <int MT, bool NT_STORE>
-void launch_ten_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+template <bool STD, int MT, bool NT_STORE>
+void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
     constexpr int TPX = 128, VPP = MT * 32;
     const int tiles_x = (a.width + TPX - 1) / TPX;
@@ -197,9 +198,9 @@ void launch_ten_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     // persistent: two workgroups per CU (2 x 80 KB of LDS), each walks tiles j, j+G, j+2G ...
     const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
     if(all_focus)
-        hipLaunchKernelGGL((lfi::blend_ten_persist<MT, true, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
+        hipLaunchKernelGGL((lfi::blend_persist<STD, MT, true, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
     else
-        hipLaunchKernelGGL((lfi::blend_ten_persist<MT, false, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
+        hipLaunchKernelGGL((lfi::blend_persist<STD, MT, false, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
 }
 
 template <int PXL, int MT>
@@ -227,26 +228,29 @@ void launch_std_valu(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 
 // first entry = default ("auto")
 const Variant kTenVariants[] = {
-    {"persist_m2_nt", launch_ten_persist<2, true>, true},
-    {"persist_m2", launch_ten_persist<2, false>, true},
-    {"direct_p1m2", launch_ten_direct<1, 2>, false},
-    {"persist_m1", launch_ten_persist<1, false>, true},
+    {"persist_m2_nt", launch_persist<false, 2, true>, true},
+    {"persist_m2", launch_persist<false, 2, false>, true},
+    {"direct_p1m2", launch_ten_direct<1, 2>, false, true},
+    {"persist_m1", launch_persist<false, 1, true>, true},
     {"lds_n1m2_w3", launch_ten_lds<1, 2, 4, 1, 64, 3>, true},
     {"lds_n1m1_w4", launch_ten_lds<1, 1, 4, 1, 64, 4>, true},
     {"lds_n2m1_w3", launch_ten_lds<2, 1, 2, 2, 64, 3>, true},
     {"lds_n1m1x8_w2", launch_ten_lds<1, 1, 4, 2, 64, 2>, true},
-    {"direct_p2m2", launch_ten_direct<2, 2>, false},
-    {"direct_p2m1", launch_ten_direct<2, 1>, false},
-    {"direct_p4m1", launch_ten_direct<4, 1>, false},
-    {"direct_p1m1", launch_ten_direct<1, 1>, false},
+    {"direct_p2m2", launch_ten_direct<2, 2>, false, true},
+    {"direct_p2m1", launch_ten_direct<2, 1>, false, true},
+    {"direct_p4m1", launch_ten_direct<4, 1>, false, true},
+    {"direct_p1m1", launch_ten_direct<1, 1>, false, true},
 };
 const Variant kStdVariants[] = {
-    {"mfma_p1m2", launch_std_mfma<1, 2>, false}, {"mfma_p2m2", launch_std_mfma<2, 2>, false}, {"mfma_p2m1", launch_std_mfma<2, 1>, false},
-    {"mfma_p4m1", launch_std_mfma<4, 1>, false}, {"valu", launch_std_valu, false},
+    {"persist_m2_nt", launch_persist<true, 2, true>, false},
+    {"persist_m1_nt", launch_persist<true, 1, true>, false},
+    {"mfma_p1m2", launch_std_mfma<1, 2>, false, true}, {"mfma_p2m2", launch_std_mfma<2, 2>, false, true}, {"mfma_p2m1", launch_std_mfma<2, 1>, false, true},
+    {"mfma_p4m1", launch_std_mfma<4, 1>, false, true}, {"valu", launch_std_valu, false, true},
 };
 const int kNumTenVariants = sizeof(kTenVariants) / sizeof(kTenVariants[0]);
 const int kNumStdVariants = sizeof(kStdVariants) / sizeof(kStdVariants[0]);
 constexpr int kGenericTenVariant = 2; // direct_p1m2: plain fp32 epilogue, any weights, pre-quantisation dump, per-batch rounding
+constexpr int kGenericStdVariant = 2; // mfma_p1m2: pre-quantisation dump
 
 int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a);
 
@@ -277,12 +281,18 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
         // the generic kernel (direct_p1m2) serves what the packed-epilogue kernels cannot: the per-batch rounding debug
         // mode, pre-quantisation dumps, and weights outside [0, 2)
         int variant = c->ten_variant;
-        if((c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) || (kTenVariants[variant].packed_epilogue && (!c->weights_scalable || a.prequant)))
+        if((c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) || (kTenVariants[variant].packed_epilogue && !c->weights_scalable) ||
+           (a.prequant && !kTenVariants[variant].prequant))
             variant = kGenericTenVariant;
         kTenVariants[variant].launch(c, a, all_focus != 0);
     }
     else if(method == LFI_METHOD_STD)
-        kStdVariants[c->std_variant].launch(c, a, all_focus != 0);
+    {
+        int variant = c->std_variant;
+        if(a.prequant && !kStdVariants[variant].prequant)
+            variant = kGenericStdVariant;
+        kStdVariants[variant].launch(c, a, all_focus != 0);
+    }
     else
         // the reference throws here (src/interpolator.cu:289-290)
         return fail(c, LFI_EINVAL, "The specified interpolation method does not exist!");
