@@ -47,6 +47,7 @@ enum {
     LFI_METHOD_STD = 0,    /* "STD":    exact-fp32 ordered FMA chain, RN-even quantisation (src/kernels.cu:289-343) */
     LFI_METHOD_TEN_WM = 1  /* "TEN_WM": fp16 matrix-core contraction, truncating quantisation (src/kernels.cu:345-462) */
 };
+#define LFI_KERNEL_FOCUS_ESTIMATE 2 /* not a render method: selects variants of FocusMap::estimate in lfi_set_variant */
 
 /* lfi_params.flags */
 enum {
@@ -147,7 +148,8 @@ int lfi_upload_map(lfi_ctx *ctx, int k, const uint8_t *rgba, size_t pitch_bytes)
 
 /* enqueue on a caller-owned hipStream_t (NULL restores the context's own stream) */
 int lfi_set_stream(lfi_ctx *ctx, void *hip_stream);
-/* choose a kernel variant by name for a method ("auto" = default); used by the benchmark harness */
+/* choose a kernel variant by name for a method — or for the focus-map estimate with LFI_KERNEL_FOCUS_ESTIMATE —
+ * ("auto" = default); used by the benchmark harness and the parity tests */
 int lfi_set_variant(lfi_ctx *ctx, int method, const char *name);
 /* comma separated variant names available for a method */
 const char *lfi_list_variants(int method);

@@ -12,7 +12,8 @@ LFI_METHOD_STD = 0
 LFI_METHOD_TEN_WM = 1
 LFI_FLAG_REFERENCE_MAP_QUIRK = 1
 LFI_FLAG_TEN_ROUND_PER_BATCH = 2
-METHODS = {"STD": LFI_METHOD_STD, "TEN_WM": LFI_METHOD_TEN_WM}
+LFI_KERNEL_FOCUS_ESTIMATE = 2
+METHODS = {"STD": LFI_METHOD_STD, "TEN_WM": LFI_METHOD_TEN_WM, "FOCUS": LFI_KERNEL_FOCUS_ESTIMATE}
 
 # every symbol include/lfi.h declares
 ABI_SYMBOLS = [

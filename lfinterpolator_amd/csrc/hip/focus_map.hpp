@@ -75,6 +75,197 @@ __global__ void __launch_bounds__(256) focus_estimate(const KernelArgs a)
     reinterpret_cast<uint32_t *>(a.maps)[(size_t)y * W + x] = m | (m << 8) | (m << 16) | 0xff000000u;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// focus_estimate_packed — the same function as focus_estimate, restructured for the L1/VALU limits that bound it
+// (9216 taps per pixel): each lane owns FOUR consecutive pixels of a row, so a tap is one 16-byte load whenever the four
+// warped coordinates are consecutive and unclamped in x (checked per lane with the exact per-pixel arithmetic; otherwise the
+// whole wave takes per-pixel clamped fetches — identical results); the per-channel min/max over the views run on
+// v_pk_min_u16 / v_pk_max_u16 with two pixels per instruction (bytes widened to u16 pairs by v_perm_b32).
+//
+// Exactness of the integer formulation against the reference's float one (src/kernels.cu:173-217): pixel values are integers
+// 0..255, so every min/max/range is an exact integer — except that the reference starts its running maximum at FLT_MIN
+// (:178), so a channel whose samples are all zero yields |0 - FLT_MIN| = FLT_MIN instead of 0.  A tap's dispersion is
+// therefore its integer range when that is ≥ 1, else FLT_MIN if any channel's maximum is zero, else 0; the float sum over the
+// nine taps equals the integer sum S when S ≥ 1 (the tiny terms are absorbed) and k·FLT_MIN otherwise, k = number of FLT_MIN
+// taps.  Comparing the keys (S > 0 ? 16·S : k), k ≤ 9, reproduces "total < best" exactly, first strict minimum included.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+template <int C>
+__device__ __forceinline__ u16x2 channel_pair(uint32_t px_a, uint32_t px_b)
+{
+    // [15:0] = byte C of px_a, [31:16] = byte C of px_b
+    constexpr uint32_t sel = 0x0c000c00u | uint32_t(C) | (uint32_t(4 + C) << 16);
+    return as_u16x2(__builtin_amdgcn_perm(px_b, px_a, sel));
+}
+
+// PPL pixels per lane (2 or 4); one wave per workgroup (a wave lives ~1 ms: fine-grained dispatch fills the tail)
+template <int PPL, int WPE>
+__global__ void __launch_bounds__(64, WPE) focus_estimate_packed(const KernelArgs a)
+{
+    constexpr int NP = PPL / 2; // pixel pairs per lane
+    const int lane = threadIdx.x & 63;
+    const int W = a.width, H = a.height;
+    const int x0 = (blockIdx.x * 64 + lane) * PPL;     // first of this lane's pixels
+    const int y = blockIdx.y;                          // one row per wave
+    if(y >= H)
+        return; // wave-uniform
+    const bool lane_active = x0 < W;
+    constexpr int STEPS = 32; // src/kernels.cu:245
+    const float step = __fdiv_rn(a.range, static_cast<float>(STEPS - 1));
+    const int rx = a.radius_x, ry = a.radius_y;
+    const uint32_t *grid32 = reinterpret_cast<const uint32_t *>(a.grid);
+    const size_t plane_px = (size_t)W * (size_t)H;
+    typedef const __attribute__((address_space(4))) float *const_float_ptr;
+    typedef const __attribute__((address_space(4))) int32_t *const_int_ptr;
+    const const_float_ptr c_offsets = (const_float_ptr)(uintptr_t)a.offsets;
+    const const_int_ptr c_ids = (const_int_ptr)(uintptr_t)a.focus_ids;
+
+    uint32_t best_key[PPL];
+    int best_i[PPL];
+#pragma unroll
+    for(int j = 0; j < PPL; j++)
+    {
+        best_key[j] = 0xffffffffu;
+        best_i[j] = 0;
+    }
+
+    for(int i = 0; i < STEPS; i++)
+    {
+        const float f = __builtin_fmaf(step, static_cast<float>(i), a.focus);
+        // running min / max per tap (9), pixel pair (2: pixels {0,1} and {2,3}) and channel (3), as u16 pairs
+        u16x2 lo[9][NP][3], hi[9][NP][3];
+#pragma unroll
+        for(int t = 0; t < 9; t++)
+#pragma unroll
+            for(int p = 0; p < NP; p++)
+#pragma unroll
+                for(int c = 0; c < 3; c++)
+                {
+                    lo[t][p][c] = as_u16x2(0x00ff00ffu);
+                    hi[t][p][c] = as_u16x2(0u);
+                }
+        for(int k = 0; k < a.n_focus_ids; k++)
+        {
+            const int g = c_ids[k];
+            const float offx = c_offsets[2 * g], offy = c_offsets[2 * g + 1];
+            const uint32_t *plane = grid32 + (size_t)g * plane_px;
+            int cx[PPL];
+#pragma unroll
+            for(int j = 0; j < PPL; j++)
+                cx[j] = warp_float(x0 + j, f, offx);
+            const int cy = warp_float(y, f, offy);
+            // 16-byte taps are valid when the four sample columns are consecutive and no x-clamp can touch them
+            bool consecutive = true;
+#pragma unroll
+            for(int j = 1; j < PPL; j++)
+                consecutive = consecutive && (cx[j] == cx[0] + j);
+            // per lane: one wide load per tap is valid when the sample columns are consecutive and no x-clamp can touch them
+            const bool vec_ok = consecutive && (cx[0] - rx >= 0) && (cx[PPL - 1] + rx <= W - 1) && (x0 + PPL - 1 < W);
+            if(lane_active)
+            {
+#pragma unroll
+                for(int ty = 0; ty < 3; ty++)
+                {
+                    const uint32_t *row = plane + (size_t)clampi(cy + (ty - 1) * ry, 0, H - 1) * W;
+#pragma unroll
+                    for(int tx = 0; tx < 3; tx++)
+                    {
+                        uint32_t px[PPL];
+                        if(vec_ok)
+                        {
+                            if constexpr(PPL == 4)
+                            {
+                                const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(row + cx[0] + (tx - 1) * rx);
+                                px[0] = v.x;
+                                px[1] = v.y;
+                                px[2] = v.z;
+                                px[3] = v.w;
+                            }
+                            else
+                            {
+                                const u32x2_a4 v = *reinterpret_cast<const u32x2_a4 *>(row + cx[0] + (tx - 1) * rx);
+                                px[0] = v.x;
+                                px[1] = v.y;
+                            }
+                        }
+                        else
+                        {
+#pragma unroll
+                            for(int j = 0; j < PPL; j++)
+                                px[j] = row[clampi(cx[j] + (tx - 1) * rx, 0, W - 1)];
+                        }
+                        const int t = tx * 3 + ty;
+#pragma unroll
+                        for(int p = 0; p < NP; p++)
+                        {
+                            const u16x2 cr = channel_pair<0>(px[2 * p], px[2 * p + 1]);
+                            const u16x2 cg = channel_pair<1>(px[2 * p], px[2 * p + 1]);
+                            const u16x2 cb = channel_pair<2>(px[2 * p], px[2 * p + 1]);
+                            lo[t][p][0] = __builtin_elementwise_min(lo[t][p][0], cr);
+                            hi[t][p][0] = __builtin_elementwise_max(hi[t][p][0], cr);
+                            lo[t][p][1] = __builtin_elementwise_min(lo[t][p][1], cg);
+                            hi[t][p][1] = __builtin_elementwise_max(hi[t][p][1], cg);
+                            lo[t][p][2] = __builtin_elementwise_min(lo[t][p][2], cb);
+                            hi[t][p][2] = __builtin_elementwise_max(hi[t][p][2], cb);
+                        }
+                    }
+                }
+            }
+        }
+        // dispersion of this focus candidate: integer sum S and FLT_MIN-tap count k per pixel
+#pragma unroll
+        for(int p = 0; p < NP; p++)
+        {
+            u16x2 sum = as_u16x2(0u), nonzero = as_u16x2(0u);
+#pragma unroll
+            for(int t = 0; t < 9; t++)
+            {
+                const u16x2 d0 = hi[t][p][0] - lo[t][p][0], d1 = hi[t][p][1] - lo[t][p][1], d2 = hi[t][p][2] - lo[t][p][2];
+                const u16x2 dmax = __builtin_elementwise_max(__builtin_elementwise_max(d0, d1), d2);
+                const u16x2 hmin = __builtin_elementwise_min(__builtin_elementwise_min(hi[t][p][0], hi[t][p][1]), hi[t][p][2]);
+                sum += dmax;
+                // a tap is a "FLT_MIN tap" iff its range is 0 and some channel's maximum is 0; flag = 0 exactly then
+                const u16x2 flag = __builtin_elementwise_min(as_u16x2(as_u32(dmax) | as_u32(hmin)), as_u16x2(0x00010001u));
+                nonzero += flag;
+            }
+#pragma unroll
+            for(int q = 0; q < 2; q++)
+            {
+                const uint32_t S = q ? (as_u32(sum) >> 16) : (as_u32(sum) & 0xffffu);
+                const uint32_t kq = 9u - (q ? (as_u32(nonzero) >> 16) : (as_u32(nonzero) & 0xffffu));
+                const uint32_t key = S > 0 ? (S << 4) : kq;
+                const int j = 2 * p + q;
+                // MinDispersion::add (src/kernels.cu:225-231): strict <, starting from FLT_MAX (every key is below 0xffffffff)
+                if(key < best_key[j])
+                {
+                    best_key[j] = key;
+                    best_i[j] = i;
+                }
+            }
+        }
+    }
+    if(!lane_active)
+        return;
+    uint32_t out[PPL];
+#pragma unroll
+    for(int j = 0; j < PPL; j++)
+    {
+        const float best_f = __builtin_fmaf(step, static_cast<float>(best_i[j]), a.focus);
+        const float normalized = __fdiv_rn(best_f - a.focus, a.range);
+        const uint32_t m = static_cast<uint32_t>(roundf(normalized * 255.0f)) & 0xffu;
+        out[j] = m | (m << 8) | (m << 16) | 0xff000000u;
+    }
+    uint32_t *dst = reinterpret_cast<uint32_t *>(a.maps) + (size_t)y * W + x0;
+#pragma unroll
+    for(int j = 0; j < PPL; j++)
+        if(x0 + j < W)
+            dst[j] = out[j];
+}
+
 __global__ void __launch_bounds__(256) focus_filter(const KernelArgs a)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,7 +67,7 @@ struct lfi_ctx
     int radius[2] = {1, 1};
     uint32_t flags = 0;
     float *prequant = nullptr;
-    int ten_variant = 0, std_variant = 0;
+    int ten_variant = 0, std_variant = 0, focus_variant = 0;
     std::string err;
 };
 
@@ -648,7 +649,12 @@ int lfi_focus_map(lfi_ctx *ctx)
     if(int rc = bind(ctx))
         return rc;
     const KernelArgs a = make_args(ctx, 0, ctx->views_n, LFI_METHOD_STD);
-    hipLaunchKernelGGL(lfi::focus_estimate, pixel_grid(ctx), dim3(256), 0, ctx->stream, a);
+    if(ctx->focus_variant == 2) // "plain": one pixel per lane, float min/max exactly as the reference writes it
+        hipLaunchKernelGGL(lfi::focus_estimate, pixel_grid(ctx), dim3(256), 0, ctx->stream, a);
+    else if(ctx->focus_variant == 1) // "packed_p4"
+        hipLaunchKernelGGL((lfi::focus_estimate_packed<4, 2>), dim3((ctx->width + 255) / 256, ctx->height), dim3(64), 0, ctx->stream, a);
+    else // "packed_p2" (default)
+        hipLaunchKernelGGL((lfi::focus_estimate_packed<2, 4>), dim3((ctx->width + 127) / 128, ctx->height), dim3(64), 0, ctx->stream, a);
     LFI_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(lfi::focus_filter, pixel_grid(ctx), dim3(256), 0, ctx->stream, a);
     LFI_HIP(ctx, hipGetLastError());
@@ -804,6 +810,8 @@ const char *lfi_list_variants(int method)
         return ten.c_str();
     if(method == LFI_METHOD_STD)
         return std_.c_str();
+    if(method == LFI_KERNEL_FOCUS_ESTIMATE)
+        return "packed_p2,packed_p4,plain";
     return "";
 }
 
@@ -837,6 +845,21 @@ int lfi_set_variant(lfi_ctx *ctx, int method, const char *name)
             if(std::strcmp(name, kStdVariants[i].name) == 0)
             {
                 ctx->std_variant = int(i);
+                return LFI_OK;
+            }
+    }
+    else if(method == LFI_KERNEL_FOCUS_ESTIMATE)
+    {
+        static const char *const names[] = {"packed_p2", "packed_p4", "plain"};
+        if(is_auto)
+        {
+            ctx->focus_variant = 0;
+            return LFI_OK;
+        }
+        for(int i = 0; i < 3; i++)
+            if(std::strcmp(name, names[i]) == 0)
+            {
+                ctx->focus_variant = i;
                 return LFI_OK;
             }
     }

@@ -292,3 +292,34 @@ def test_weights_outside_unit_range_use_the_generic_kernel(gpu, oracle_c):
         ctx.sync()
         assert np.abs(ctx.download_views().astype(int) - m16b.astype(int)).max() <= TEN_TOL_LSB, variant
     ctx.close()
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 384, 6), (15, 15, 301, 5), (4, 4, 130, 3)], ids=lambda s: "x".join(map(str, s)))
+def test_focus_map_wide_rows(shape, gpu, oracle_c):
+    """Rows wide enough for the packed focus-estimate kernel's wide-load path (interior lanes) next to its per-pixel
+    clamped path (border lanes, ragged right edge): both must give the oracle's bytes."""
+    cols, rows, W, H = shape
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.06, 0.24, 7.0, 2.276, 4)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, 21)
+    # piecewise-constant content so that the dispersion has real minima (random noise ties everywhere at 255)
+    lf = (lf // 64 * 64).astype(np.uint8)
+    lf[..., 3] = 255
+    ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    want0 = oracle_c.focus_estimate(lf, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, threads=8)
+    for variant in ctx.list_variants("FOCUS"):
+        ctx.set_variant("FOCUS", variant)
+        ctx.focus_map()
+        ctx.sync()
+        assert (ctx.download_map(0) == want0).all(), variant
+        assert (ctx.download_map(1) == oracle_c.focus_filter(want0, hp.block_radius)).all(), variant
+    # an all-black grid exercises the reference's FLT_MIN initial maximum (src/kernels.cu:178): every candidate ties at
+    # 9*FLT_MIN, the first one wins → map 0 everywhere
+    ctx2 = _ctx(gpu, cols, rows, W, H, hp, lf=np.zeros_like(lf))
+    want_black = oracle_c.focus_estimate(np.zeros_like(lf), hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, threads=8)
+    for variant in ctx2.list_variants("FOCUS"):
+        ctx2.set_variant("FOCUS", variant)
+        ctx2.focus_map()
+        ctx2.sync()
+        assert (ctx2.download_map(0) == want_black).all(), variant
+    ctx.close()
+    ctx2.close()
