@@ -87,14 +87,21 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a one-GPU box: LFI_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two ranks on one
+    # device).  The real multi-GPU run is one rank per GPU over RCCL ("nccl").
+    rehearse = os.environ.get("LFI_BENCH_REHEARSE") == "1"
+    device_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_images = COLS * ROWS
-    ctx = L.Context(local_rank)
+    ctx = L.Context(device_index)
     ctx.set_grid(COLS, ROWS, WIDTH, HEIGHT)
     # input planes live in a torch tensor so that RCCL (torch.distributed "nccl") can broadcast into them
     grid = torch.empty((n_images, HEIGHT, WIDTH, 4), dtype=torch.uint8, device=dev)
@@ -170,7 +177,7 @@ def main() -> int:
             "config": {"workload": f"{COLS}x{ROWS} LF @{WIDTH}x{HEIGHT}, {VIEWS_PER_GPU}-view -t trajectory per GPU, "
                                    f"-m {args.method}, -f {FOCUS} -a {ASPECT} -s {EFFECT:g}",
                        "views_per_gpu": VIEWS_PER_GPU, "images": n_images, "variant": args.variant,
-                       "parallelism": f"views sharded over {world} GPU(s), grid broadcast once (RCCL)"},
+                       "parallelism": f"views sharded over {world} GPU(s), grid broadcast once ({'gloo rehearsal' if rehearse else 'RCCL'})"},
             "gpix_per_s": value * WIDTH * HEIGHT / 1e9,
             "prewarm_ms": args.prewarm_ms,
             "kernel_ms_per_launch": t_launch * 1e3,
