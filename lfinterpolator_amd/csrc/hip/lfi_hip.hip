@@ -250,8 +250,16 @@ const Variant kStdVariants[] = {
 };
 const int kNumTenVariants = sizeof(kTenVariants) / sizeof(kTenVariants[0]);
 const int kNumStdVariants = sizeof(kStdVariants) / sizeof(kStdVariants[0]);
-constexpr int kGenericTenVariant = 2; // direct_p1m2: plain fp32 epilogue, any weights, pre-quantisation dump, per-batch rounding
-constexpr int kGenericStdVariant = 2; // mfma_p1m2: pre-quantisation dump
+int find_variant(const Variant *table, int n, const char *name)
+{
+    for(int i = 0; i < n; i++)
+        if(std::strcmp(table[i].name, name) == 0)
+            return i;
+    return 0;
+}
+// the generic kernels: plain fp32 epilogue, any weights, pre-quantisation dump, per-batch rounding (TEN_WM)
+const int kGenericTenVariant = find_variant(kTenVariants, kNumTenVariants, "direct_p1m2");
+const int kGenericStdVariant = find_variant(kStdVariants, kNumStdVariants, "mfma_p1m2");
 
 int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a);
 
