@@ -266,6 +266,190 @@ __global__ void __launch_bounds__(64, WPE) focus_estimate_packed(const KernelArg
             dst[j] = out[j];
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// focus_estimate_lds — packed formulation with the source window staged in LDS.
+// The packed kernel above is limited by L1 tag traffic: nine taps per (view, candidate) per pixel, each wave-load touching
+// two cache lines per lane-quad, although the three x-taps overlap almost completely.  Here one wave = 128 pixels of a row
+// (lane l owns pixels l and l+64).  For each (candidate, view) the wave copies the three source rows it needs — a window of
+// 128 + 2·rx + 2·SLACK pixels starting just left of lane 0's sample — with ONE 16 B/lane load per row into LDS, and all
+// 18 taps of a lane are conflict-free ds_read_b32 at its exact per-pixel coordinates.  The window of the NEXT (candidate, view)
+// is fetched into registers while the current one is processed.  If any lane's taps would leave the staged window or touch an
+// x-clamp (image borders; the odd float-rounding outlier is covered by SLACK), the wave falls back to per-pixel clamped
+// fetches for that iteration.  Same integer (sum, FLT_MIN-count) key as focus_estimate_packed: bit-exact.
+constexpr int FOCUS_LDS_ROW = 256; // window pixels per row (max 128 + 2*rx + 2*SLACK)
+constexpr int FOCUS_LDS_SLACK = 4;
+
+__global__ void __launch_bounds__(64, 4) focus_estimate_lds(const KernelArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t win[3 * FOCUS_LDS_ROW];
+    const int lane = threadIdx.x & 63;
+    const int W = a.width, H = a.height;
+    const int X0 = blockIdx.x * 128;
+    const int y = blockIdx.y;
+    const int xa = X0 + lane, xb = X0 + 64 + lane; // this lane's two pixels
+    constexpr int STEPS = 32;                      // src/kernels.cu:245
+    const float step = __fdiv_rn(a.range, static_cast<float>(STEPS - 1));
+    const int rx = a.radius_x, ry = a.radius_y;
+    const int need = 128 + 2 * rx + 2 * FOCUS_LDS_SLACK; // ≤ FOCUS_LDS_ROW, checked by the host
+    const uint32_t *grid32 = reinterpret_cast<const uint32_t *>(a.grid);
+    const size_t plane_px = (size_t)W * (size_t)H;
+    typedef const __attribute__((address_space(4))) float *const_float_ptr;
+    typedef const __attribute__((address_space(4))) int32_t *const_int_ptr;
+    const const_float_ptr c_offsets = (const_float_ptr)(uintptr_t)a.offsets;
+    const const_int_ptr c_ids = (const_int_ptr)(uintptr_t)a.focus_ids;
+    const int n_ids = a.n_focus_ids;
+    const int total = STEPS * n_ids;
+
+    // per-iteration geometry: everything a (candidate i, view k) pair needs to stage and to tap
+    struct Geo
+    {
+        const uint32_t *plane;
+        int cxa, cxb, cy, wx0;
+        bool fast;
+    };
+    auto geometry = [&](int i, int k) -> Geo {
+        const float f = __builtin_fmaf(step, static_cast<float>(i), a.focus);
+        const int g = c_ids[k];
+        const float offx = c_offsets[2 * g], offy = c_offsets[2 * g + 1];
+        Geo q;
+        q.plane = grid32 + (size_t)g * plane_px;
+        q.cxa = warp_float(xa, f, offx);
+        q.cxb = warp_float(xb, f, offx);
+        q.cy = warp_float(y, f, offy);
+        q.wx0 = __builtin_amdgcn_readfirstlane(q.cxa) - rx - FOCUS_LDS_SLACK;
+        const bool in_a = xa >= W || (q.cxa - rx >= q.wx0 && q.cxa + rx < q.wx0 + need);
+        const bool in_b = xb >= W || (q.cxb - rx >= q.wx0 && q.cxb + rx < q.wx0 + need);
+        const bool ok = in_a && in_b && q.wx0 >= 0 && q.wx0 + need <= W;
+        q.fast = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
+        return q;
+    };
+    auto fetch_rows = [&](const Geo &q, u32x4 (&rows)[3]) {
+        if(q.fast && 4 * lane < need)
+        {
+#pragma unroll
+            for(int ty = 0; ty < 3; ty++)
+                rows[ty] = *reinterpret_cast<const u32x4_a4 *>(q.plane + (size_t)clampi(q.cy + (ty - 1) * ry, 0, H - 1) * W + q.wx0 + 4 * lane);
+        }
+    };
+
+    uint32_t best_key[2] = {0xffffffffu, 0xffffffffu};
+    int best_i[2] = {0, 0};
+    u16x2 lo[9][3], hi[9][3]; // [tap][channel], u16 pair = (pixel a, pixel b)
+
+    Geo cur = geometry(0, 0);
+    u32x4 rows[3];
+    fetch_rows(cur, rows);
+    int i = 0, k = 0;
+    for(int it = 0; it < total; it++)
+    {
+        if(k == 0)
+        {
+#pragma unroll
+            for(int t = 0; t < 9; t++)
+#pragma unroll
+                for(int c = 0; c < 3; c++)
+                {
+                    lo[t][c] = as_u16x2(0x00ff00ffu);
+                    hi[t][c] = as_u16x2(0u);
+                }
+        }
+        // stage the current window (its loads were issued one iteration ago) …
+        if(cur.fast && 4 * lane < need)
+        {
+#pragma unroll
+            for(int ty = 0; ty < 3; ty++)
+                *reinterpret_cast<u32x4 *>(win + ty * FOCUS_LDS_ROW + 4 * lane) = rows[ty];
+        }
+        // … and start fetching the next one
+        Geo nxt = cur;
+        const int nk = k + 1 == n_ids ? 0 : k + 1, ni = k + 1 == n_ids ? i + 1 : i;
+        if(it + 1 < total)
+        {
+            nxt = geometry(ni, nk);
+            fetch_rows(nxt, rows);
+        }
+        // taps (single-wave workgroup: the LDS queue is in order, so the reads below see the writes above)
+        uint32_t pa[9], pb[9];
+        if(cur.fast)
+        {
+            const uint32_t *wa = win + (cur.cxa - cur.wx0), *wb = win + (cur.cxb - cur.wx0);
+#pragma unroll
+            for(int ty = 0; ty < 3; ty++)
+#pragma unroll
+                for(int tx = 0; tx < 3; tx++)
+                {
+                    pa[tx * 3 + ty] = wa[ty * FOCUS_LDS_ROW + (tx - 1) * rx];
+                    pb[tx * 3 + ty] = wb[ty * FOCUS_LDS_ROW + (tx - 1) * rx];
+                }
+        }
+        else
+        {
+#pragma unroll
+            for(int ty = 0; ty < 3; ty++)
+            {
+                const uint32_t *row = cur.plane + (size_t)clampi(cur.cy + (ty - 1) * ry, 0, H - 1) * W;
+#pragma unroll
+                for(int tx = 0; tx < 3; tx++)
+                {
+                    pa[tx * 3 + ty] = row[clampi(cur.cxa + (tx - 1) * rx, 0, W - 1)];
+                    pb[tx * 3 + ty] = row[clampi(cur.cxb + (tx - 1) * rx, 0, W - 1)];
+                }
+            }
+        }
+#pragma unroll
+        for(int t = 0; t < 9; t++)
+        {
+            const u16x2 cr = channel_pair<0>(pa[t], pb[t]), cg = channel_pair<1>(pa[t], pb[t]), cb = channel_pair<2>(pa[t], pb[t]);
+            lo[t][0] = __builtin_elementwise_min(lo[t][0], cr);
+            hi[t][0] = __builtin_elementwise_max(hi[t][0], cr);
+            lo[t][1] = __builtin_elementwise_min(lo[t][1], cg);
+            hi[t][1] = __builtin_elementwise_max(hi[t][1], cg);
+            lo[t][2] = __builtin_elementwise_min(lo[t][2], cb);
+            hi[t][2] = __builtin_elementwise_max(hi[t][2], cb);
+        }
+        if(k == n_ids - 1)
+        {
+            u16x2 sum = as_u16x2(0u), nonzero = as_u16x2(0u);
+#pragma unroll
+            for(int t = 0; t < 9; t++)
+            {
+                const u16x2 d0 = hi[t][0] - lo[t][0], d1 = hi[t][1] - lo[t][1], d2 = hi[t][2] - lo[t][2];
+                const u16x2 dmax = __builtin_elementwise_max(__builtin_elementwise_max(d0, d1), d2);
+                const u16x2 hmin = __builtin_elementwise_min(__builtin_elementwise_min(hi[t][0], hi[t][1]), hi[t][2]);
+                sum += dmax;
+                nonzero += __builtin_elementwise_min(as_u16x2(as_u32(dmax) | as_u32(hmin)), as_u16x2(0x00010001u));
+            }
+#pragma unroll
+            for(int q = 0; q < 2; q++)
+            {
+                const uint32_t S = q ? (as_u32(sum) >> 16) : (as_u32(sum) & 0xffffu);
+                const uint32_t kq = 9u - (q ? (as_u32(nonzero) >> 16) : (as_u32(nonzero) & 0xffffu));
+                const uint32_t key = S > 0 ? (S << 4) : kq;
+                if(key < best_key[q])
+                {
+                    best_key[q] = key;
+                    best_i[q] = i;
+                }
+            }
+        }
+        cur = nxt;
+        i = ni;
+        k = nk;
+    }
+#pragma unroll
+    for(int q = 0; q < 2; q++)
+    {
+        const int x = q ? xb : xa;
+        if(x < W)
+        {
+            const float best_f = __builtin_fmaf(step, static_cast<float>(best_i[q]), a.focus);
+            const float normalized = __fdiv_rn(best_f - a.focus, a.range);
+            const uint32_t m = static_cast<uint32_t>(roundf(normalized * 255.0f)) & 0xffu;
+            reinterpret_cast<uint32_t *>(a.maps)[(size_t)y * W + x] = m | (m << 8) | (m << 16) | 0xff000000u;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) focus_filter(const KernelArgs a)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);

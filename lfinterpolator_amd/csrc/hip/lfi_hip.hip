@@ -657,11 +657,15 @@ int lfi_focus_map(lfi_ctx *ctx)
     if(int rc = bind(ctx))
         return rc;
     const KernelArgs a = make_args(ctx, 0, ctx->views_n, LFI_METHOD_STD);
-    if(ctx->focus_variant == 2) // "plain": one pixel per lane, float min/max exactly as the reference writes it
+    // the LDS-staged kernel needs its window (128 + 2·radius_x + slack pixels) to fit a 256-pixel LDS row
+    const bool lds_fits = 128 + 2 * ctx->radius[0] + 2 * lfi::FOCUS_LDS_SLACK <= lfi::FOCUS_LDS_ROW;
+    if(ctx->focus_variant == 0 && lds_fits) // "lds" (default)
+        hipLaunchKernelGGL(lfi::focus_estimate_lds, dim3((ctx->width + 127) / 128, ctx->height), dim3(64), 0, ctx->stream, a);
+    else if(ctx->focus_variant == 3) // "plain": one pixel per lane, float min/max exactly as the reference writes it
         hipLaunchKernelGGL(lfi::focus_estimate, pixel_grid(ctx), dim3(256), 0, ctx->stream, a);
-    else if(ctx->focus_variant == 1) // "packed_p4"
+    else if(ctx->focus_variant == 2) // "packed_p4"
         hipLaunchKernelGGL((lfi::focus_estimate_packed<4, 2>), dim3((ctx->width + 255) / 256, ctx->height), dim3(64), 0, ctx->stream, a);
-    else // "packed_p2" (default)
+    else // "packed_p2" (also the fallback of "lds" for very large radii)
         hipLaunchKernelGGL((lfi::focus_estimate_packed<2, 4>), dim3((ctx->width + 127) / 128, ctx->height), dim3(64), 0, ctx->stream, a);
     LFI_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(lfi::focus_filter, pixel_grid(ctx), dim3(256), 0, ctx->stream, a);
@@ -819,7 +823,7 @@ const char *lfi_list_variants(int method)
     if(method == LFI_METHOD_STD)
         return std_.c_str();
     if(method == LFI_KERNEL_FOCUS_ESTIMATE)
-        return "packed_p2,packed_p4,plain";
+        return "lds,packed_p2,packed_p4,plain";
     return "";
 }
 
@@ -858,13 +862,13 @@ int lfi_set_variant(lfi_ctx *ctx, int method, const char *name)
     }
     else if(method == LFI_KERNEL_FOCUS_ESTIMATE)
     {
-        static const char *const names[] = {"packed_p2", "packed_p4", "plain"};
+        static const char *const names[] = {"lds", "packed_p2", "packed_p4", "plain"};
         if(is_auto)
         {
             ctx->focus_variant = 0;
             return LFI_OK;
         }
-        for(int i = 0; i < 3; i++)
+        for(int i = 0; i < 4; i++)
             if(std::strcmp(name, names[i]) == 0)
             {
                 ctx->focus_variant = i;

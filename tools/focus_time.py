@@ -6,9 +6,13 @@ for (cols, rows, W, H) in ((8, 8, 1920, 1080), (15, 15, 1920, 1080), (15, 15, 38
     ctx = L.Context(0); ctx.set_grid(cols, rows, W, H); ctx.fill_synthetic(0x1F1F)
     hp = L.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.22, 0.17, 7.0, 1.783, 64)
     ctx.set_params(hp); ctx.sync()
-    ctx.focus_map(); ctx.sync()
-    t0 = time.perf_counter(); ctx.focus_map(); ctx.sync(); t1 = time.perf_counter()
-    msg = f"{cols}x{rows} @{W}x{H}: focus_map (estimate+filter) {1e3*(t1-t0):.2f} ms"
+    msg = f"{cols}x{rows} @{W}x{H}: focus_map (estimate+filter)"
+    for variant in ctx.list_variants("FOCUS"):
+        ctx.set_variant("FOCUS", variant)
+        ctx.focus_map(); ctx.sync()
+        t0 = time.perf_counter(); ctx.focus_map(); ctx.sync(); t1 = time.perf_counter()
+        msg += f" {variant} {1e3*(t1-t0):.2f} ms"
+    ctx.set_variant("FOCUS", "auto")
     for method in ("TEN_WM", "STD"):
         st = ctx.benchmark(method, all_focus=True, warmup=1, runs=3)
         msg += f" | all-focus {method} {st.median_ms:.3f} ms"
