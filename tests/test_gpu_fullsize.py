@@ -21,13 +21,22 @@ def _shifted(img, ox, oy):
     return out
 
 
-@pytest.mark.parametrize("cfg", [(8, 8, 1920, 1080, 64, "0,0,1,1", 0.23, 1.783),
-                                 (15, 15, 1920, 1080, 45, "0,0.5,1,0.5", 0.06, 2.276)],
-                         ids=["config2_8x8_1080p_64v", "config3_15x15_1080p_45v"])
+# (cols, rows, W, H, views rendered, trajectory, focus, aspect, total views of the job, rank, world, oracle row bands?)
+CONFIGS = [
+    (8, 8, 1920, 1080, 64, "0,0,1,1", 0.23, 1.783, 64, 0, 1, True),          # BASELINE config 2
+    (15, 15, 1920, 1080, 45, "0,0.5,1,0.5", 0.06, 2.276, 45, 0, 1, True),    # config 3: 45-view quilt sweep
+    (8, 8, 3840, 2160, 32, "0,0,1,1", 0.23, 1.783, 256, 3, 8, True),         # config 4: rank 3 of 8, views [96,128) of 256
+    (15, 15, 3840, 2160, 64, "0.071,0.071,0.93,0.93", 0.22, 1.783, 64, 0, 1, False),  # config 5 (7.5 GB grid: no host copy)
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=["config2_8x8_1080p_64v", "config3_15x15_1080p_45v", "config4_8x8_4k_rank3of8",
+                                              "config5_15x15_4k_64v"])
 def test_full_size_properties(cfg, gpu, oracle_c):
-    cols, rows, W, H, V, traj, focus, aspect = cfg
+    cols, rows, W, H, V, traj, focus, aspect, total_views, rank, world, with_bands = cfg
     n = cols * rows
-    hp = gpu.build_params(cols, rows, W, H, traj, focus, 0.0, 3.0, aspect, V)
+    hp, v_first, v_last = gpu.rank_params(cols, rows, W, H, traj, focus, 0.0, 3.0, aspect, total_views, world, rank)
+    assert v_last - v_first == V
     ctx = gpu.Context(0)
     ctx.set_grid(cols, rows, W, H)
     ctx.fill_synthetic(SEED)
@@ -51,14 +60,14 @@ def test_full_size_properties(cfg, gpu, oracle_c):
     # (2) oracle row bands with the real weights
     hp.weights = real_weights
     ctx.set_params(hp)
-    lf = oracle_c.synthetic_lf(n, W, H, SEED)
+    lf = oracle_c.synthetic_lf(n, W, H, SEED) if with_bands else None
     ctx.render("STD")
     ctx.sync()
     std_views = {v: ctx.download_view(v) for v in probe}
     ctx.render("TEN_WM")
     ctx.sync()
     ten_views = {v: ctx.download_view(v) for v in probe}
-    for y0, y1 in ((0, 2), (H // 2, H // 2 + 2), (H - 2, H)):
+    for y0, y1 in ((0, 2), (H // 2, H // 2 + 2), (H - 2, H)) if with_bands else ():
         for v in probe:
             ref = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, v0=v, v1=v + 1, rows=(y0, y1))
             assert (std_views[v][y0:y1] == ref[v, y0:y1]).all(), ("STD", v, y0)
