@@ -59,12 +59,12 @@ __device__ __forceinline__ void quantize_tile_rn(const f32x16 &cr, const f32x16 
     }
 }
 
-template <int MT>
+template <int MT, int KC_>
 struct PersistCfg
 {
     static constexpr int NW = 4;                 // waves per workgroup, side by side along the row
     static constexpr int TPX = 128;              // pixels per tile: 32 per wave, one per lane column
-    static constexpr int KC = 64;                // images per chunk
+    static constexpr int KC = KC_;               // images per chunk (64, or 32 to fit more workgroups per CU)
     static constexpr int VPP = MT * 32;          // views per pass
     static constexpr int PX_DW = KC * TPX;       // dwords of pixels per pixel buffer (32 KB)
     static constexpr int W_DW = (KC / 8) * VPP * 4; // dwords of weight fragments per weight buffer: [k-octet][view] × 16 B
@@ -73,11 +73,11 @@ struct PersistCfg
 
 // STD = false: TEN_WM (fp16 MFMA, packed truncating epilogue, weights ×2^15);  STD = true: the exact-fp32 path of
 // Kernels::Standard::process (reference src/kernels.cu:289-343) on v_mfma_f32_32x32x2_f32 — see blend_std.hpp — in the same pipeline.
-template <bool STD, int MT, bool ALLFOCUS, bool NT_STORE>
-__global__ void __launch_bounds__(256, 2)
+template <bool STD, int MT, bool ALLFOCUS, bool NT_STORE, int KC_ = 64, int WGS = 2>
+__global__ void __launch_bounds__(256, WGS)
     blend_persist(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes)
 {
-    using C = PersistCfg<MT>;
+    using C = PersistCfg<MT, KC_>;
     constexpr int TPX = C::TPX, KC = C::KC, VPP = C::VPP, KS = KC / 16;
     __shared__ __attribute__((aligned(16))) uint32_t lds[C::LDS_DW];
 

@@ -189,19 +189,19 @@ void launch_ten_lds(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
         hipLaunchKernelGGL((lfi::blend_ten_lds<NT, MT, WPX, WV, KC, WPE, false>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
 }
 
-template <bool STD, int MT, bool NT_STORE>
+template <bool STD, int MT, bool NT_STORE, int KC = 64, int WGS = 2>
 void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
     constexpr int TPX = 128, VPP = MT * 32;
     const int tiles_x = (a.width + TPX - 1) / TPX;
     const int n_tiles = tiles_x * a.height;
     const int passes = (a.v1 - a.v0 + VPP - 1) / VPP;
-    // persistent: two workgroups per CU (2 x 80 KB of LDS), each walks tiles j, j+G, j+2G ...
-    const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    // persistent: WGS workgroups per CU (2 x 80 KB of LDS at KC = 64), each walks tiles j, j+G, j+2G ...
+    const dim3 grid(std::min(n_tiles, WGS * cu_count_of(c))), block(256);
     if(all_focus)
-        hipLaunchKernelGGL((lfi::blend_persist<STD, MT, true, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
+        hipLaunchKernelGGL((lfi::blend_persist<STD, MT, true, NT_STORE, KC, WGS>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
     else
-        hipLaunchKernelGGL((lfi::blend_persist<STD, MT, false, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
+        hipLaunchKernelGGL((lfi::blend_persist<STD, MT, false, NT_STORE, KC, WGS>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
 }
 
 template <int PXL, int MT>
