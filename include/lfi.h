@@ -142,6 +142,10 @@ int lfi_sync(lfi_ctx *ctx);
 /* ---- results: replaces storeResults' cudaMemcpy2DFromArray (src/interpolator.cu:309).  Synchronous. --------- */
 int lfi_download_view(lfi_ctx *ctx, int v, uint8_t *rgba, size_t pitch_bytes);
 int lfi_download_map(lfi_ctx *ctx, int k, uint8_t *rgba, size_t pitch_bytes);
+/* Views v0 … v0+tiles_x*tiles_y-1 as ONE image of tiles_x × tiles_y tiles, filled left to right, top to bottom — what
+ * scripts/viewsToQuilt.sh builds with ImageMagick `montage -tile 5x9` from the NN.png files (Looking-Glass quilt).
+ * rgba: (tiles_y*H) rows of pitch_bytes ≥ tiles_x*W*4.  Synchronous. */
+int lfi_download_quilt(lfi_ctx *ctx, int tiles_x, int tiles_y, int v0, uint8_t *rgba, size_t pitch_bytes);
 int lfi_upload_map(lfi_ctx *ctx, int k, const uint8_t *rgba, size_t pitch_bytes); /* tests: inject a focus map */
 
 /* ---- plumbing ------------------------------------------------------------------------------------------------- */

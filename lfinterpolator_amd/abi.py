@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "lfi_create", "lfi_destroy", "lfi_last_error", "lfi_abi_version", "lfi_device_count", "lfi_set_grid",
     "lfi_upload_image", "lfi_attach_grid", "lfi_grid_device_ptr", "lfi_fill_synthetic", "lfi_set_params",
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
-    "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_upload_map", "lfi_set_stream",
+    "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
 ]
 
@@ -75,6 +75,7 @@ def load_hip_library() -> C.CDLL:
         "lfi_sync": (i, [vp]),
         "lfi_download_view": (i, [vp, i, vp, sz]),
         "lfi_download_map": (i, [vp, i, vp, sz]),
+        "lfi_download_quilt": (i, [vp, i, i, i, vp, sz]),
         "lfi_upload_map": (i, [vp, i, vp, sz]),
         "lfi_set_stream": (i, [vp, vp]),
         "lfi_set_variant": (i, [vp, i, C.c_char_p]),
@@ -239,6 +240,11 @@ class Context:
     def download_views(self, v0: int = 0, v1: int | None = None) -> np.ndarray:
         v1 = self.views if v1 is None else v1
         return np.stack([self.download_view(v) for v in range(v0, v1)])
+
+    def download_quilt(self, tiles_x: int, tiles_y: int, v0: int = 0) -> np.ndarray:
+        out = np.empty((tiles_y * self.height, tiles_x * self.width, 4), dtype=np.uint8)
+        self._check(self._lib.lfi_download_quilt(self._h, tiles_x, tiles_y, v0, _ptr(out), tiles_x * self.width * 4))
+        return out
 
     def download_map(self, k: int) -> np.ndarray:
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)

@@ -792,6 +792,31 @@ int lfi_download_map(lfi_ctx *ctx, int k, uint8_t *rgba, size_t pitch_bytes)
     return LFI_OK;
 }
 
+int lfi_download_quilt(lfi_ctx *ctx, int tiles_x, int tiles_y, int v0, uint8_t *rgba, size_t pitch_bytes)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->views || !ctx->have_params)
+        return fail(ctx, LFI_EINVAL, "nothing rendered yet");
+    if(tiles_x < 1 || tiles_y < 1 || v0 < 0 || (long)v0 + (long)tiles_x * tiles_y > ctx->views_n)
+        return fail(ctx, LFI_EINVAL, "quilt needs tiles_x*tiles_y views starting at v0 inside [0, views)");
+    if(!rgba || pitch_bytes < (size_t)tiles_x * ctx->width * 4)
+        return fail(ctx, LFI_EINVAL, "bad quilt pointer or pitch");
+    if(int rc = bind(ctx))
+        return rc;
+    // one strided device→host copy per tile straight into its place in the quilt: no staging buffer, no extra kernel
+    for(int ty = 0; ty < tiles_y; ty++)
+        for(int tx = 0; tx < tiles_x; tx++)
+        {
+            const int v = v0 + ty * tiles_x + tx;
+            uint8_t *dst = rgba + (size_t)ty * ctx->height * pitch_bytes + (size_t)tx * ctx->width * 4;
+            LFI_HIP(ctx, hipMemcpy2DAsync(dst, pitch_bytes, ctx->views + plane_bytes(ctx) * v, (size_t)ctx->width * 4,
+                                          (size_t)ctx->width * 4, ctx->height, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LFI_OK;
+}
+
 int lfi_upload_map(lfi_ctx *ctx, int k, const uint8_t *rgba, size_t pitch_bytes)
 {
     if(!ctx)

@@ -127,4 +127,15 @@ void Interpolator::storeResults(std::string path)
         lfi::writePng(fileName.string(), resolution.x, resolution.y, static_cast<int>(channels), data.data(), pitch);
         bar.add();
     }
+    if(quiltTiles.x > 0 && quiltTiles.y > 0)
+    {
+        if(quiltTiles.x * quiltTiles.y > viewCount)
+            throw std::runtime_error("The quilt has more tiles than rendered views!");
+        std::cout << "Storing quilt..." << std::endl;
+        const size_t quiltPitch = pitch * quiltTiles.x;
+        std::vector<uint8_t> quilt(quiltPitch * resolution.y * quiltTiles.y);
+        check(lfi_download_quilt(context, quiltTiles.x, quiltTiles.y, 0, quilt.data(), quiltPitch));
+        lfi::writePng((std::filesystem::path(path) / "quilt.png").string(), resolution.x * quiltTiles.x, resolution.y * quiltTiles.y,
+                      static_cast<int>(channels), quilt.data(), quiltPitch);
+    }
 }

@@ -23,6 +23,8 @@ class Interpolator
         void setBenchmarkRuns(size_t runs) { kernelBenchmarkRuns = runs; } // reference: 100 (src/interpolator.h:13)
         static void setDefaultDevice(int index) { defaultDevice = index; } // GPU used by Interpolator(path)
         void setReferenceMapQuirk(bool on) { referenceMapQuirk = on; }
+        // also write quilt.png: the views as one image of cols × rows tiles (what scripts/viewsToQuilt.sh montages, 5×9 there)
+        void setQuilt(lfi::IVec2 tiles) { quiltTiles = tiles; }
         float lastAverageTime() const { return averageTime; }
 
         // synthetic cols×rows grid of width×height images instead of a directory
@@ -34,6 +36,7 @@ class Interpolator
         static int defaultDevice;
         int device{defaultDevice};
         bool referenceMapQuirk{false};
+        lfi::IVec2 quiltTiles{0, 0};
         lfi_ctx *context{nullptr};
         float focus{0};
         float range{0};

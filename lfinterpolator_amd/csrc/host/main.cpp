@@ -35,6 +35,7 @@ int main(int argc, char **argv)
                           "-n - number of views rendered along the trajectory (default=64)\n"
                           "-b - number of timed kernel launches (default=100)\n"
                           "-d - GPU index (default=0)\n"
+                          "-q - also store quilt.png: the first cols*rows views as cols,rows tiles (e.g. 5,9 for a Looking Glass quilt)\n"
                           "--synthetic cols,rows,width,height[,seed] - use a generated light field instead of -i\n"
                         };
     if(args.printHelpIfPresent(helpText))
@@ -80,6 +81,14 @@ int main(int argc, char **argv)
             interpolator->setViewCount(static_cast<int>(args["-n"]));
         if(args["-b"])
             interpolator->setBenchmarkRuns(static_cast<size_t>(static_cast<int>(args["-b"])));
+        if(args["-q"])
+        {
+            std::stringstream spec(static_cast<std::string>(args["-q"]));
+            std::string a, b;
+            if(!std::getline(spec, a, ',') || !std::getline(spec, b, ','))
+                throw std::runtime_error("-q expects cols,rows");
+            interpolator->setQuilt({std::stoi(a), std::stoi(b)});
+        }
         interpolator->interpolate(outputPath, trajectory, focus, range, method, effect, aspect);
     }
     catch(const std::exception &e)

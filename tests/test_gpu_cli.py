@@ -76,3 +76,19 @@ def test_cli_errors_and_help(gpu, tmp_path):
     assert res.returncode != 0 and "The specified interpolation method does not exist!" in res.stderr
     res = _run(gpu, "--synthetic", "3,3,256,256", "-o", str(tmp_path / "o1"), "-t", "0,0,1,1", "-m", "TEN_WM", "-n", "1", "-b", "2")
     assert res.returncode == 0 and os.listdir(tmp_path / "o1") == ["00.png"]   # BASELINE config 1's shape on the GPU path
+
+
+def test_cli_quilt(gpu, oracle_c, tmp_path):
+    """-q cols,rows writes quilt.png = the NN.png tiles montaged left to right, top to bottom (scripts/viewsToQuilt.sh)."""
+    dst = tmp_path / "out"
+    res = _run(gpu, "--synthetic", "4,4,48,20", "-o", str(dst), "-t", "0,0.5,1,0.5", "-m", "TEN_WM", "-f", "0.1", "-n", "6", "-q", "3,2",
+               "-b", "1")
+    assert res.returncode == 0, res.stderr
+    quilt = np.array(Image.open(dst / "quilt.png"))
+    assert quilt.shape == (2 * 20, 3 * 48, 4)
+    for v in range(6):
+        tile = np.array(Image.open(dst / f"{v:02d}.png"))
+        ty, tx = divmod(v, 3)
+        assert (quilt[ty * 20:(ty + 1) * 20, tx * 48:(tx + 1) * 48] == tile).all()
+    res = _run(gpu, "--synthetic", "4,4,48,20", "-o", str(dst), "-t", "0,0,1,1", "-m", "STD", "-n", "4", "-q", "3,2", "-b", "1")
+    assert res.returncode != 0 and "more tiles than rendered views" in res.stderr

@@ -234,6 +234,23 @@ def test_view_range_sharding_is_exact(gpu):
     ctx.close()
 
 
+def test_quilt_download(gpu):
+    cols = rows = 3
+    W, H, V = 40, 12, 10
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.2, 0.0, 3.0, 1.0, V)
+    ctx = _ctx(gpu, cols, rows, W, H, hp)
+    ctx.render("STD")
+    ctx.sync()
+    views = ctx.download_views()
+    quilt = ctx.download_quilt(4, 2, v0=1)
+    for i in range(8):
+        ty, tx = divmod(i, 4)
+        assert (quilt[ty * H:(ty + 1) * H, tx * W:(tx + 1) * W] == views[1 + i]).all()
+    with pytest.raises(gpu.LfiError, match="quilt needs"):
+        ctx.download_quilt(4, 3)
+    ctx.close()
+
+
 def test_error_behaviour(gpu):
     ctx = gpu.Context(0)
     with pytest.raises(gpu.LfiError, match="lfi_set_grid"):
