@@ -148,6 +148,10 @@ int lfi_download_map(lfi_ctx *ctx, int k, uint8_t *rgba, size_t pitch_bytes);
 int lfi_download_quilt(lfi_ctx *ctx, int tiles_x, int tiles_y, int v0, uint8_t *rgba, size_t pitch_bytes);
 int lfi_upload_map(lfi_ctx *ctx, int k, const uint8_t *rgba, size_t pitch_bytes); /* tests: inject a focus map */
 
+/* Page-locked host memory for uploads / downloads at full PCIe rate (hipHostMalloc); optional — any host pointer works. */
+int lfi_alloc_pinned(size_t bytes, void **out_ptr);
+int lfi_free_pinned(void *ptr);
+
 /* ---- plumbing ------------------------------------------------------------------------------------------------- */
 
 /* enqueue on a caller-owned hipStream_t (NULL restores the context's own stream) */

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "lfi_create", "lfi_destroy", "lfi_last_error", "lfi_abi_version", "lfi_device_count", "lfi_set_grid",
     "lfi_upload_image", "lfi_attach_grid", "lfi_grid_device_ptr", "lfi_fill_synthetic", "lfi_set_params",
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
-    "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_upload_map", "lfi_set_stream",
+    "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
 ]
 
@@ -76,6 +76,8 @@ def load_hip_library() -> C.CDLL:
         "lfi_download_view": (i, [vp, i, vp, sz]),
         "lfi_download_map": (i, [vp, i, vp, sz]),
         "lfi_download_quilt": (i, [vp, i, i, i, vp, sz]),
+        "lfi_alloc_pinned": (i, [sz, C.POINTER(vp)]),
+        "lfi_free_pinned": (i, [vp]),
         "lfi_upload_map": (i, [vp, i, vp, sz]),
         "lfi_set_stream": (i, [vp, vp]),
         "lfi_set_variant": (i, [vp, i, C.c_char_p]),

@@ -817,6 +817,27 @@ int lfi_download_quilt(lfi_ctx *ctx, int tiles_x, int tiles_y, int v0, uint8_t *
     return LFI_OK;
 }
 
+int lfi_alloc_pinned(size_t bytes, void **out_ptr)
+{
+    if(!out_ptr || bytes == 0)
+        return LFI_EINVAL;
+    *out_ptr = nullptr;
+    const hipError_t e = hipHostMalloc(out_ptr, bytes, hipHostMallocDefault);
+    if(e != hipSuccess)
+    {
+        g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? LFI_ENOMEM : LFI_EHIP;
+    }
+    return LFI_OK;
+}
+
+int lfi_free_pinned(void *ptr)
+{
+    if(!ptr)
+        return LFI_OK;
+    return hipHostFree(ptr) == hipSuccess ? LFI_OK : LFI_EHIP;
+}
+
 int lfi_upload_map(lfi_ctx *ctx, int k, const uint8_t *rgba, size_t pitch_bytes)
 {
     if(!ctx)

@@ -3,9 +3,14 @@
 // estimate the focus map, run the benchmark loop, store NN.png (+ mapK.png).
 #include "interpolator.h"
 
+#include <algorithm>
+#include <condition_variable>
 #include <filesystem>
+#include <future>
 #include <iostream>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 #include "image_io.h"
 #include "lfLoader.h"
@@ -105,6 +110,9 @@ void Interpolator::interpolate(std::string outputPath, std::string trajectory, f
 
 void Interpolator::storeResults(std::string path)
 {
+    // Same files as the reference (NN.png, mapK.png: src/interpolator.cu:299-316).  The device→host copies land in a ring of
+    // page-locked buffers and the PNG encoding runs on worker threads, so the GPU copy of view i+1 overlaps the compression
+    // of view i (the reference downloads and encodes one view at a time on one thread).
     std::cout << "Storing results..." << std::endl;
     constexpr int MAP_COUNT{2};
     int count = viewCount;
@@ -113,20 +121,65 @@ void Interpolator::storeResults(std::string path)
     std::filesystem::create_directories(path);
     LoadingBar bar(count);
     const size_t pitch = static_cast<size_t>(resolution.x) * channels;
-    std::vector<uint8_t> data(pitch * resolution.y, 255);
+    const size_t imageBytes = pitch * resolution.y;
+    const int workers = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const int slots = workers + 1;
+    uint8_t *ring = nullptr;
+    const bool pinned = lfi_alloc_pinned(imageBytes * slots, reinterpret_cast<void **>(&ring)) == LFI_OK;
+    std::vector<uint8_t> pageable;
+    if(!pinned)
+    {
+        pageable.resize(imageBytes * slots);
+        ring = pageable.data();
+    }
+    std::mutex mutex;
+    std::condition_variable slotFree;
+    std::vector<bool> busy(slots, false);
+    std::vector<std::future<void>> jobs;
+    std::string firstError;
     for(int i = 0; i < count; i++)
     {
+        int slot;
+        {
+            std::unique_lock<std::mutex> lock(mutex);
+            slotFree.wait(lock, [&] { return std::find(busy.begin(), busy.end(), false) != busy.end(); });
+            slot = static_cast<int>(std::find(busy.begin(), busy.end(), false) - busy.begin());
+            busy[slot] = true;
+        }
+        uint8_t *data = ring + imageBytes * slot;
         auto fileName = std::filesystem::path(path) / (std::string(((i < 10) ? "0" : "")) + std::to_string(i) + ".png");
         if(i >= viewCount)
         {
             fileName = std::filesystem::path(path) / ("map" + std::to_string(i - viewCount) + ".png");
-            check(lfi_download_map(context, i - viewCount, data.data(), pitch));
+            check(lfi_download_map(context, i - viewCount, data, pitch));
         }
         else
-            check(lfi_download_view(context, i, data.data(), pitch));
-        lfi::writePng(fileName.string(), resolution.x, resolution.y, static_cast<int>(channels), data.data(), pitch);
+            check(lfi_download_view(context, i, data, pitch));
+        jobs.push_back(std::async(std::launch::async, [&, slot, data, fileName] {
+            try
+            {
+                lfi::writePng(fileName.string(), resolution.x, resolution.y, static_cast<int>(channels), data, pitch);
+            }
+            catch(const std::exception &e)
+            {
+                std::lock_guard<std::mutex> lock(mutex);
+                if(firstError.empty())
+                    firstError = e.what();
+            }
+            {
+                std::lock_guard<std::mutex> lock(mutex);
+                busy[slot] = false;
+            }
+            slotFree.notify_one();
+        }));
         bar.add();
     }
+    for(auto &job : jobs)
+        job.get();
+    if(pinned)
+        lfi_free_pinned(ring);
+    if(!firstError.empty())
+        throw std::runtime_error(firstError);
     if(quiltTiles.x > 0 && quiltTiles.y > 0)
     {
         if(quiltTiles.x * quiltTiles.y > viewCount)
