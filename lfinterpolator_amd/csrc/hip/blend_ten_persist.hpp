@@ -96,7 +96,38 @@ __global__ void __launch_bounds__(256, WGS)
     const const_float_ptr c_offsets = (const_float_ptr)(uintptr_t)a.offsets;
 
     // ---- issue the LDS-DMA of one unit (tile t, view pass `pass`, chunk k0) into buffer b ------------------------------------
-    auto issue = [&](int t, int pass, int k0, int pb, int wb, bool with_pixels) {
+    // integer offsets of this lane's image in each of the wave's DMA slots (slot j ↔ image pair wave + NW*j of a chunk):
+    // all scalar loads of a chunk are issued back to back (one wait), and when the whole stack fits one chunk they are
+    // loaded once for the kernel — the offsets do not depend on the tile
+    constexpr int SLOTS = KC / 2 / C::NW;
+    struct SlotOffsets
+    {
+        int ox[SLOTS], oy[SLOTS];
+    };
+    auto load_offsets = [&](int k0) {
+        SlotOffsets so;
+        const int kn = min(min(KC, a.k_pad - k0), a.n_images - k0);
+        int o0x[SLOTS], o0y[SLOTS], o1x[SLOTS], o1y[SLOTS];
+#pragma unroll
+        for(int j = 0; j < SLOTS; j++)
+        {
+            const int q = wave + C::NW * j;
+            const int g0 = min(k0 + 2 * q, k0 + max(kn, 1) - 1), g1 = min(g0 + 1, k0 + max(kn, 1) - 1);
+            o0x[j] = c_focused[2 * g0];
+            o0y[j] = c_focused[2 * g0 + 1];
+            o1x[j] = c_focused[2 * g1];
+            o1y[j] = c_focused[2 * g1 + 1];
+        }
+#pragma unroll
+        for(int j = 0; j < SLOTS; j++)
+        {
+            so.ox[j] = h ? o1x[j] : o0x[j];
+            so.oy[j] = h ? o1y[j] : o0y[j];
+        }
+        return so;
+    };
+
+    auto issue = [&](int t, int pass, int k0, int pb, int wb, bool with_pixels, const SlotOffsets &so) {
         const int y = t / tiles_x;
         const int x0 = (t - y * tiles_x) * TPX;
         const int kc = min(KC, a.k_pad - k0);
@@ -117,37 +148,43 @@ __global__ void __launch_bounds__(256, WGS)
             return; // a later view pass of a single-chunk tile: the pixels are already in LDS
         if constexpr(!ALLFOCUS)
         {
-            // pixels: 16 B/lane pieces, two images per instruction (half-wave hh ↔ image 2q+hh, lane column c ↔ pixels 4c…4c+3)
-            for(int q = wave; 2 * q < kn; q += C::NW)
+            // pixels: 16 B/lane pieces, two images per instruction (half-wave hh ↔ image 2q+hh, lane column c ↔ pixels 4c…4c+3);
+            // slot j of this wave is image pair q = wave + NW*j
+#pragma unroll
+            for(int j = 0; j < SLOTS; j++)
             {
-                const int g0 = k0 + 2 * q;                     // wave-uniform → scalar loads of the offsets
-                const int g1 = min(g0 + 1, k0 + kn - 1);       // odd tail: the second half reloads the last image
-                const lfi_int2 o0 = {c_focused[2 * g0], c_focused[2 * g0 + 1]}, o1 = {c_focused[2 * g1], c_focused[2 * g1 + 1]};
-                const int ox = h ? o1.x : o0.x, oy = h ? o1.y : o0.y;
-                const int g = h ? g1 : g0;
-                const int sy = clampi(y + oy, 0, H - 1);
-                const int sx = x0 + ox + 4 * r;
-                const bool inside = (sx >= 0) && (sx + 4 <= W) && (2 * q + 1 < kn || h == 0);
-                const bool all_inside = __builtin_amdgcn_ballot_w64(inside) == ~0ull;
-                if(all_inside)
-                    dma16(grid32 + (size_t)g * plane_px + (size_t)sy * W + sx, px_addr + uint32_t(q) * 1024u);
-                else
+                const int q = wave + C::NW * j;
+                if(2 * q < kn)
                 {
-                    // a run crosses the left/right border (or the tile is ragged): per-pixel clamp-to-edge addresses
-                    // (reference src/kernels.cu:125), 64 pixels per instruction
-#pragma unroll
-                    for(int img = 0; img < 2; img++)
+                    const int g0 = k0 + 2 * q;
+                    const int g1 = min(g0 + 1, k0 + kn - 1);       // odd tail: the second half reloads the last image
+                    const int ox = so.ox[j], oy = so.oy[j];         // this half-wave's image: g0 (h = 0) or g1 (h = 1)
+                    const int g = h ? g1 : g0;
+                    const int sy = clampi(y + oy, 0, H - 1);
+                    const int sx = x0 + ox + 4 * r;
+                    const bool inside = (sx >= 0) && (sx + 4 <= W) && (2 * q + 1 < kn || h == 0);
+                    const bool all_inside = __builtin_amdgcn_ballot_w64(inside) == ~0ull;
+                    if(all_inside)
+                        dma16(grid32 + (size_t)g * plane_px + (size_t)sy * W + sx, px_addr + uint32_t(q) * 1024u);
+                    else
                     {
-                        if(2 * q + img >= kn)
-                            break;
-                        const lfi_int2 oo = img ? o1 : o0;
-                        const int syy = clampi(y + oo.y, 0, H - 1);
-                        const uint32_t *row = grid32 + (size_t)(g0 + img) * plane_px + (size_t)syy * W;
+                        // a run crosses the left/right border (or the tile is ragged): per-pixel clamp-to-edge addresses
+                        // (reference src/kernels.cu:125), 64 pixels per instruction; the other half-wave's offsets come by DPP-free
+                        // broadcast through readlane (wave-uniform per image)
 #pragma unroll
-                        for(int s = 0; s < 2; s++)
+                        for(int img = 0; img < 2; img++)
                         {
-                            const int sxx = clampi(x0 + oo.x + 64 * s + lane, 0, W - 1);
-                            dma4(row + sxx, px_addr + uint32_t(2 * q + img) * 512u + uint32_t(s) * 256u);
+                            if(2 * q + img >= kn)
+                                break;
+                            const int oxi = __builtin_amdgcn_readlane(ox, img * 32), oyi = __builtin_amdgcn_readlane(oy, img * 32);
+                            const int syy = clampi(y + oyi, 0, H - 1);
+                            const uint32_t *row = grid32 + (size_t)(g0 + img) * plane_px + (size_t)syy * W;
+#pragma unroll
+                            for(int s = 0; s < 2; s++)
+                            {
+                                const int sxx = clampi(x0 + oxi + 64 * s + lane, 0, W - 1);
+                                dma4(row + sxx, px_addr + uint32_t(2 * q + img) * 512u + uint32_t(s) * 256u);
+                            }
                         }
                     }
                 }
@@ -183,7 +220,8 @@ __global__ void __launch_bounds__(256, WGS)
         return;
     int pass = 0, k0 = 0, pbuf = 0, wbuf = 0;
     int prev_stores = 0; // store instructions this wave issued in the previous epilogue (they are the youngest VMEM ops)
-    issue(t, 0, 0, 0, 0, true);
+    SlotOffsets slot_offsets = load_offsets(0);
+    issue(t, 0, 0, 0, 0, true, slot_offsets);
 
     f32x16 acc[MT][3];
 #pragma unroll
@@ -228,7 +266,11 @@ __global__ void __launch_bounds__(256, WGS)
         __builtin_amdgcn_s_barrier(); // everybody's pieces have landed; everybody is done with the buffers about to be refilled
         asm volatile("" ::: "memory");
         if(have_next)
-            issue(nt, npass, nk0, npbuf, wbuf ^ 1, next_needs_pixels);
+        {
+            if(!single_chunk && !ALLFOCUS)
+                slot_offsets = load_offsets(nk0);
+            issue(nt, npass, nk0, npbuf, wbuf ^ 1, next_needs_pixels, slot_offsets);
+        }
 
         // ---- compute the current unit ------------------------------------------------------------------------------------------------
         const int kc = min(KC, a.k_pad - k0);
@@ -274,26 +316,34 @@ __global__ void __launch_bounds__(256, WGS)
             // exact fp32: MFMA q of a k-step multiplies image pair (16ks+2q, 16ks+2q+1): k = 0 ↔ lower half-wave, k = 1 ↔ upper,
             // accumulated in that order = the reference's ascending-g fmaf chain (src/kernels.cu:328-338)
             const uint32_t *col = px_buf + wave * 32 + r + h * TPX;
+            // raw LDS words of one k-step: this half-wave's 8 pixels (images 2q + h) and this lane's view row of the fp16
+            // weights for the 16 images (two octets; image 2q+h sits in bits [16h, 16h+16) of dword q).  The reads of k-step
+            // ks+1 are issued BEFORE the 48 MFMAs of k-step ks (register double buffer, scheduling barrier), so the matrix
+            // pipe never waits for LDS latency inside the loop.
+            uint32_t px[2][8];
+            u32x4 wlo[2][MT], whi[2][MT];
+            auto load_step = [&](int ks, int slot) {
+#pragma unroll
+                for(int q = 0; q < 8; q++)
+                    px[slot][q] = col[(16 * ks + 2 * q) * TPX];
+#pragma unroll
+                for(int m = 0; m < MT; m++)
+                {
+                    wlo[slot][m] = w_buf[(2 * ks) * VPP + m * 32 + r];
+                    whi[slot][m] = w_buf[(2 * ks + 1) * VPP + m * 32 + r];
+                }
+            };
+            const uint32_t sh = 16u * uint32_t(h);
+            load_step(0, 0);
 #pragma unroll
             for(int ks = 0; ks < KS; ks++)
             {
                 if(16 * ks < kc)
                 {
-                    // pixels of this half-wave's 8 images (2q + h) of the k-step, all requested before the first use
-                    uint32_t px[8];
-#pragma unroll
-                    for(int q = 0; q < 8; q++)
-                        px[q] = col[(16 * ks + 2 * q) * TPX];
-                    // this lane's view row of the fp16 weights for the 16 images of the k-step: two octets of 8 halves;
-                    // image 2q+h sits in bits [16h, 16h+16) of dword q
-                    u32x4 wlo[MT], whi[MT];
-#pragma unroll
-                    for(int m = 0; m < MT; m++)
-                    {
-                        wlo[m] = w_buf[(2 * ks) * VPP + m * 32 + r];
-                        whi[m] = w_buf[(2 * ks + 1) * VPP + m * 32 + r];
-                    }
-                    const uint32_t sh = 16u * uint32_t(h);
+                    const int cur = ks & 1;
+                    if(ks + 1 < KS && 16 * (ks + 1) < kc)
+                        load_step(ks + 1, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for(int q = 0; q < 8; q++)
                     {
@@ -301,10 +351,10 @@ __global__ void __launch_bounds__(256, WGS)
 #pragma unroll
                         for(int m = 0; m < MT; m++)
                         {
-                            const uint32_t d = q < 4 ? wlo[m][q] : whi[m][q - 4];
+                            const uint32_t d = q < 4 ? wlo[cur][m][q] : whi[cur][m][q - 4];
                             wq[m] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(d >> sh))); // exact
                         }
-                        const uint32_t p = px[q];
+                        const uint32_t p = px[cur][q];
                         const float pc[3] = {static_cast<float>(p & 0xffu), static_cast<float>((p >> 8) & 0xffu),
                                              static_cast<float>((p >> 16) & 0xffu)};
 #pragma unroll
