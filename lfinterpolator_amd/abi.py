@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -48,6 +49,14 @@ def load_hip_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime under the same soname (libamdhip64.so.7) as /opt/rocm's, and the first one a
+    # process loads wins.  If ours pulled in /opt/rocm's first, a later `import torch` would find "No HIP GPUs"; so when torch is
+    # installed it goes first (bench.py and the distributed path need it anyway).  The C++ host code is unaffected.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(HIP_LIB):
         raise LfiError(f"{HIP_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950); lfinterpolator_amd has no CPU fallback")

@@ -1,0 +1,102 @@
+"""GPU (-m gpu): the plumbing entry points of the C-ABI — caller-owned device memory, streams, timers, the benchmark loop,
+two contexts side by side — and bench.py's JSON contract."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SEED
+
+pytestmark = pytest.mark.gpu
+
+
+def test_attached_buffers_and_caller_stream(gpu, oracle_c):
+    torch = pytest.importorskip("torch")
+    cols = rows = 4
+    W, H, V = 96, 16, 8
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.2, 0.0, 3.0, 1.5, V)
+    lf = oracle_c.synthetic_lf(16, W, H, SEED)
+    dev = torch.device("cuda", 0)
+    grid = torch.from_numpy(lf).to(dev)
+    views = torch.zeros((V, H, W, 4), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.attach_grid(grid.data_ptr(), grid.numel())
+    ctx.set_params(hp)
+    ctx.attach_views(views.data_ptr(), views.numel())
+    assert ctx.grid_device_ptr() == (grid.data_ptr(), grid.numel())
+    assert ctx.views_device_ptr() == (views.data_ptr(), views.numel())
+    ctx.set_stream(stream.cuda_stream)
+    ctx.render("STD")
+    stream.synchronize()
+    want = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)
+    assert (views.cpu().numpy() == want).all()          # the kernel wrote into the caller's tensor on the caller's stream
+    ctx.set_stream(None)
+    with pytest.raises(gpu.LfiError, match="smaller than"):
+        ctx.attach_views(views.data_ptr(), 16)
+    ctx.close()
+    assert (views.cpu().numpy() == want).all()          # attached memory survives the context
+
+
+def test_timer_and_benchmark_stats(gpu):
+    ctx = gpu.Context(0)
+    ctx.set_grid(4, 4, 256, 64)
+    ctx.fill_synthetic(1)
+    ctx.set_params(gpu.build_params(4, 4, 256, 64, "0,0,1,1", 0.1, 0.0, 3.0, 1.0, 16))
+    st = ctx.benchmark("TEN_WM", warmup=1, runs=5)
+    assert st.runs == 5 and 0 < st.min_ms <= st.median_ms <= st.max_ms and st.mean_ms > 0 and st.back_to_back_ms > 0
+    ctx.timer_start()
+    for _ in range(3):
+        ctx.render("STD")
+    assert ctx.timer_stop() > 0
+    ctx.close()
+
+
+def test_two_contexts_are_independent(gpu, oracle_c):
+    a, b = gpu.Context(0), gpu.Context(0)
+    a.set_grid(3, 3, 40, 10)
+    b.set_grid(2, 2, 24, 6)
+    a.fill_synthetic(5)
+    b.fill_synthetic(6)
+    ha = gpu.build_params(3, 3, 40, 10, "0,0,1,1", 0.3, 0.0, 3.0, 1.0, 4)
+    hb = gpu.build_params(2, 2, 24, 6, "1,0,0,1", 0.1, 0.0, 2.0, 1.0, 3)
+    a.set_params(ha)
+    b.set_params(hb)
+    a.render("TEN_WM")
+    b.render("STD")
+    a.sync()
+    b.sync()
+    assert (b.download_views() == oracle_c.blend_std(oracle_c.synthetic_lf(4, 24, 6, 6), hb.focused_offsets, hb.offsets, hb.weights)).all()
+    ten = oracle_c.blend_ten(oracle_c.synthetic_lf(9, 40, 10, 5), ha.focused_offsets, ha.offsets, ha.weights)
+    assert np.abs(a.download_views().astype(int) - ten.astype(int)).max() <= 1
+    with pytest.raises(gpu.LfiError):
+        a.render("STD", v0=0, v1=99)
+    b.render("STD")  # an error on one context leaves the other usable
+    b.sync()
+    a.close()
+    b.close()
+
+
+def test_bench_json_contract(gpu):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--prewarm-ms", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "views/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.05 < r["frac"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "views/s" and "sample" in c
+    assert d["value"] > 100 * c["value"]
