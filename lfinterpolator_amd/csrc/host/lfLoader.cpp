@@ -3,8 +3,12 @@
 // non-square grids and unpadded numbers work; every image must have the same resolution and every grid cell a file.
 #include "lfLoader.h"
 
+#include <algorithm>
+#include <atomic>
 #include <iostream>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 #include "image_io.h"
 #include "loadingbar.hpp"
@@ -77,11 +81,43 @@ void LfLoader::loadData(std::string path)
 
     std::cout << "Loading images..." << std::endl;
     LoadingBar bar(files.size());
-    for(auto const &file : files)
+    // decode on several threads (the reference decodes one file after another with stb_image); every image goes to its own
+    // grid cell, the shared resolution is checked afterwards
+    std::vector<std::filesystem::path> list(files.begin(), files.end());
+    std::vector<lfi::Image> decoded(list.size());
+    std::vector<std::string> errors(list.size());
+    const unsigned workers = std::max(1u, std::min<unsigned>(16u, std::thread::hardware_concurrency()));
+    std::atomic<size_t> next{0};
+    std::mutex barMutex;
+    std::vector<std::thread> pool;
+    for(unsigned w = 0; w < std::min<size_t>(workers, list.size()); w++)
+        pool.emplace_back([&] {
+            for(size_t i = next++; i < list.size(); i = next++)
+            {
+                try
+                {
+                    decoded[i] = lfi::loadImage((std::filesystem::path(path) / list[i]).string());
+                }
+                catch(const std::exception &e)
+                {
+                    errors[i] = e.what();
+                }
+                std::lock_guard<std::mutex> lock(barMutex);
+                bar.add();
+            }
+        });
+    for(auto &t : pool)
+        t.join();
+    constexpr int RGBA_CHANNELS{4};
+    for(size_t i = 0; i < list.size(); i++)
     {
-        auto rowCol = parseFilename(file.string());
-        loadImage((std::filesystem::path(path) / file).string(), {rowCol.y, rowCol.x});
-        bar.add();
+        if(!errors[i].empty())
+            throw std::runtime_error(errors[i]);
+        auto rowCol = parseFilename(list[i].string());
+        if(resolution.x != 0 && (resolution.x != decoded[i].width || resolution.y != decoded[i].height))
+            throw std::runtime_error("Image " + (std::filesystem::path(path) / list[i]).string() + " does not have the same resolution as the others");
+        resolution = {decoded[i].width, decoded[i].height, RGBA_CHANNELS};
+        grid[rowCol.y][rowCol.x] = std::move(decoded[i].pixels);
     }
     for(int col = 0; col < colsRows.x; col++)
         for(int row = 0; row < colsRows.y; row++)
