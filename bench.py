@@ -63,6 +63,10 @@ def main() -> int:
     ap.add_argument("--method", default="TEN_WM", choices=["TEN_WM", "STD"])
     ap.add_argument("--variant", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", default="views", choices=["views", "rows"],
+                    help="views (default, the contract's weak-scaling run): 64 views per GPU, every GPU holds the whole grid; "
+                         "rows: strong scaling of ONE 64-view render — each GPU renders a band of rows and holds only the "
+                         "input rows the band's warp reaches (SURVEY.md §8(f).2)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed launches during set-up, before the W warm-up steps, so that the clocks have ramped "
                          "(with 5 warm-up launches = 1 ms of work the first timed launches still run at idle clocks)")
@@ -103,23 +107,38 @@ def main() -> int:
     n_images = COLS * ROWS
     ctx = L.Context(device_index)
     ctx.set_grid(COLS, ROWS, WIDTH, HEIGHT)
-    # input planes live in a torch tensor so that RCCL (torch.distributed "nccl") can broadcast into them
-    grid = torch.empty((n_images, HEIGHT, WIDTH, 4), dtype=torch.uint8, device=dev)
-    ctx.attach_grid(grid.data_ptr(), grid.numel())
     stream = torch.cuda.Stream(device=dev)
-    ctx.set_stream(stream.cuda_stream)
-    if rank == 0:
+    if args.shard == "views":
+        # input planes live in a torch tensor so that RCCL (torch.distributed "nccl") can broadcast into them
+        grid = torch.empty((n_images, HEIGHT, WIDTH, 4), dtype=torch.uint8, device=dev)
+        ctx.attach_grid(grid.data_ptr(), grid.numel())
+        ctx.set_stream(stream.cuda_stream)
+        if rank == 0:
+            ctx.fill_synthetic(SEED)
+            ctx.sync()
+        L.broadcast_grid(grid, src=0)    # the one collective of the job: 531 MB over xGMI (RCCL), outside the timed region
+        torch.cuda.synchronize()
+        # host parameters for the whole trajectory; each rank keeps its own rows of the weight matrix
+        total_views = VIEWS_PER_GPU * world
+        hp, v0, v1 = L.rank_params(COLS, ROWS, WIDTH, HEIGHT, TRAJECTORY, FOCUS, 0.0, EFFECT, ASPECT, total_views, world, rank)
+        assert v1 - v0 == VIEWS_PER_GPU
+        in_rows_n = out_rows_n = HEIGHT
+    else:
+        # one 64-view render split into row bands: no collective at all with synthetic data (every rank generates the rows it
+        # holds; real data would be scattered band + halo per rank)
+        total_views = VIEWS_PER_GPU
+        hp = L.build_params(COLS, ROWS, WIDTH, HEIGHT, TRAJECTORY, FOCUS, 0.0, EFFECT, ASPECT, total_views)
+        band = L.row_band(HEIGHT, world, rank)
+        held = L.input_rows(band, hp.focused_offsets, HEIGHT)
+        ctx.set_row_window(band[0], band[1], held[0], held[1])
+        in_rows_n, out_rows_n = held[1] - held[0], band[1] - band[0]
+        grid = torch.empty((n_images, in_rows_n, WIDTH, 4), dtype=torch.uint8, device=dev)
+        ctx.attach_grid(grid.data_ptr(), grid.numel())
+        ctx.set_stream(stream.cuda_stream)
         ctx.fill_synthetic(SEED)
         ctx.sync()
-    L.broadcast_grid(grid, src=0)    # the one collective of the job: 531 MB over xGMI (RCCL), outside the timed region
-    torch.cuda.synchronize()
-
-    # host parameters for the whole trajectory; each rank keeps its own rows of the weight matrix
-    total_views = VIEWS_PER_GPU * world
-    hp, v0, v1 = L.rank_params(COLS, ROWS, WIDTH, HEIGHT, TRAJECTORY, FOCUS, 0.0, EFFECT, ASPECT, total_views, world, rank)
-    assert v1 - v0 == VIEWS_PER_GPU
     ctx.set_params(hp)
-    views = torch.empty((VIEWS_PER_GPU, HEIGHT, WIDTH, 4), dtype=torch.uint8, device=dev)
+    views = torch.empty((VIEWS_PER_GPU, out_rows_n, WIDTH, 4), dtype=torch.uint8, device=dev)
     ctx.attach_views(views.data_ptr(), views.numel())
     ctx.set_variant(args.method, args.variant)
 
@@ -152,12 +171,13 @@ def main() -> int:
     elapsed_max, kernel_s_max = float(t[0]), float(t[1])
 
     # cheap sanity check that the timed launches rendered something: alpha must be 255 everywhere, RGB not constant
-    sample = views[0, HEIGHT // 2, :64].cpu().numpy()
+    sample = views[0, out_rows_n // 2, :64].cpu().numpy()
     assert (sample[:, 3] == 255).all() and sample[:, :3].std() > 0, "render produced no image"
 
     if rank == 0:
         value = total_views * args.steps / elapsed_max
-        b_alg = 4.0 * WIDTH * HEIGHT * (n_images + VIEWS_PER_GPU)       # bytes per launch per GPU
+        # bytes per launch on this GPU: rows held of every input plane + rows rendered of every view
+        b_alg = 4.0 * WIDTH * (in_rows_n * n_images + out_rows_n * VIEWS_PER_GPU)
         t_launch = kernel_s_max / args.steps
         achieved = b_alg / t_launch / 1e9
         traffic = None
@@ -171,20 +191,24 @@ def main() -> int:
             "metric": "novel views/sec + Gpix/sec, 8x8 LF @1080p TEN_WM" if args.method == "TEN_WM"
                       else "novel views/sec + Gpix/sec, 8x8 LF @1080p STD",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if args.shard == "views" else "strong",
             "vs_baseline": None,
             "dtype": "f16" if args.method == "TEN_WM" else "f32", "data": "synthetic",
             "config": {"workload": f"{COLS}x{ROWS} LF @{WIDTH}x{HEIGHT}, {VIEWS_PER_GPU}-view -t trajectory per GPU, "
                                    f"-m {args.method}, -f {FOCUS} -a {ASPECT} -s {EFFECT:g}",
                        "views_per_gpu": VIEWS_PER_GPU, "images": n_images, "variant": args.variant,
-                       "parallelism": f"views sharded over {world} GPU(s), grid broadcast once ({'gloo rehearsal' if rehearse else 'RCCL'})"},
+                       "parallelism": (f"views sharded over {world} GPU(s), grid broadcast once ({'gloo rehearsal' if rehearse else 'RCCL'})"
+                                       if args.shard == "views" else
+                                       f"rows sharded over {world} GPU(s): {out_rows_n} output rows from {in_rows_n} input rows on rank 0, "
+                                       "no collective")},
             "gpix_per_s": value * WIDTH * HEIGHT / 1e9,
             "prewarm_ms": args.prewarm_ms,
             "kernel_ms_per_launch": t_launch * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "frac_of_measured_copy_6290": achieved / 6290.0,
-                         "mfma_frac_of_2500_tflops": 6.0 * n_images * VIEWS_PER_GPU * WIDTH * HEIGHT / t_launch / 2.5e15},
+                         "mfma_frac_of_2500_tflops": 6.0 * n_images * VIEWS_PER_GPU * WIDTH * out_rows_n / t_launch / 2.5e15},
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)

@@ -106,6 +106,12 @@ int lfi_device_count(void);
 
 /* Declare a cols×rows grid of width×height RGBA8 images and allocate N = cols*rows input planes + 2 focus maps. */
 int lfi_set_grid(lfi_ctx *ctx, int cols, int rows, int width, int height);
+/* Row window for spatial (row-band) multi-GPU sharding — SURVEY.md §8(f).2; no counterpart in the reference.  After
+ * lfi_set_grid: this context renders output rows [out_y0, out_y1) only and holds input rows [in_y0, in_y1) of every image only
+ * (band + the halo the warp reaches into); planes shrink accordingly, so G GPUs each read and write ≈1/G of the bytes.  Host
+ * pointers passed to upload / download / quilt calls keep addressing row 0 of the WHOLE image; attached device buffers hold
+ * the window's rows only.  lfi_set_params verifies that the input rows cover every sampled row.  Fixed-focus renders only. */
+int lfi_set_row_window(lfi_ctx *ctx, int out_y0, int out_y1, int in_y0, int in_y1);
 /* cudaMemcpy2DToArray of one image (src/interpolator.cu:91): copies; the caller keeps ownership.  Synchronous. */
 int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_bytes);
 /* Use caller-owned device memory ([N][H][W][4] u8, ≥ N*H*W*4 bytes) for the input planes instead of the context's

@@ -10,9 +10,9 @@ from .abi import (LFI_METHOD_STD, LFI_METHOD_TEN_WM, LFI_FLAG_REFERENCE_MAP_QUIR
                   Context, LfiError, load_hip_library, ABI_SYMBOLS)
 from .host import HostParams, build_params, load_host_library, load_image, write_png, load_grid
 from .build import build_all
-from .sharding import view_range, rank_params, broadcast_grid
+from .sharding import view_range, rank_params, broadcast_grid, row_band, input_rows
 from . import build
 
 __all__ = ["LFI_METHOD_STD", "LFI_METHOD_TEN_WM", "LFI_FLAG_REFERENCE_MAP_QUIRK", "LFI_FLAG_TEN_ROUND_PER_BATCH",
            "Context", "LfiError", "load_hip_library", "ABI_SYMBOLS", "HostParams", "build_params", "load_host_library", "load_image", "write_png", "load_grid",
-           "build_all", "view_range", "rank_params", "broadcast_grid"]
+           "build_all", "view_range", "rank_params", "broadcast_grid", "row_band", "input_rows"]

@@ -18,7 +18,7 @@ METHODS = {"STD": LFI_METHOD_STD, "TEN_WM": LFI_METHOD_TEN_WM, "FOCUS": LFI_KERN
 
 # every symbol include/lfi.h declares
 ABI_SYMBOLS = [
-    "lfi_create", "lfi_destroy", "lfi_last_error", "lfi_abi_version", "lfi_device_count", "lfi_set_grid",
+    "lfi_create", "lfi_destroy", "lfi_last_error", "lfi_abi_version", "lfi_device_count", "lfi_set_grid", "lfi_set_row_window",
     "lfi_upload_image", "lfi_attach_grid", "lfi_grid_device_ptr", "lfi_fill_synthetic", "lfi_set_params",
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
     "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
@@ -69,6 +69,7 @@ def load_hip_library() -> C.CDLL:
         "lfi_abi_version": (i, []),
         "lfi_device_count": (i, []),
         "lfi_set_grid": (i, [vp, i, i, i, i]),
+        "lfi_set_row_window": (i, [vp, i, i, i, i]),
         "lfi_upload_image": (i, [vp, i, vp, sz]),
         "lfi_attach_grid": (i, [vp, vp, sz]),
         "lfi_grid_device_ptr": (i, [vp, C.POINTER(vp), C.POINTER(sz)]),
@@ -151,6 +152,12 @@ class Context:
     def set_grid(self, cols: int, rows: int, width: int, height: int) -> None:
         self._check(self._lib.lfi_set_grid(self._h, cols, rows, width, height))
         self.cols, self.rows, self.width, self.height = cols, rows, width, height
+        self.out_rows = (0, height)
+
+    def set_row_window(self, out_y0: int, out_y1: int, in_y0: int, in_y1: int) -> None:
+        """Render rows [out_y0, out_y1) only, holding input rows [in_y0, in_y1) only (row-band sharding)."""
+        self._check(self._lib.lfi_set_row_window(self._h, out_y0, out_y1, in_y0, in_y1))
+        self.out_rows = (out_y0, out_y1)
 
     def upload_image(self, g: int, rgba: np.ndarray) -> None:
         rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
@@ -244,7 +251,8 @@ class Context:
 
     # -- results -------------------------------------------------------------------------------------------------
     def download_view(self, v: int) -> np.ndarray:
-        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        """Whole-image array; with a row window only rows [out_y0, out_y1) are filled (the rest stays zero)."""
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
         self._check(self._lib.lfi_download_view(self._h, v, _ptr(out), self.width * 4))
         return out
 

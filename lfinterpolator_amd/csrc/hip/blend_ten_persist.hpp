@@ -86,7 +86,8 @@ __global__ void __launch_bounds__(256, WGS)
     const int r = lane & 31, h = lane >> 5;
     const int W = a.width, H = a.height;
     const uint32_t *grid32 = reinterpret_cast<const uint32_t *>(a.grid);
-    const size_t plane_px = (size_t)W * (size_t)H;
+    const size_t plane_px = (size_t)W * (size_t)a.in_rows;      // one input plane as held by this context
+    const size_t oplane_px = (size_t)W * (size_t)a.out_rows;    // one output plane
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr_t)lds)));
     // the offset tables are read through the scalar cache (constant address space): wave-uniform, and counted by lgkmcnt, so
     // they never touch the vmcnt bookkeeping of the pipeline
@@ -128,8 +129,9 @@ __global__ void __launch_bounds__(256, WGS)
     };
 
     auto issue = [&](int t, int pass, int k0, int pb, int wb, bool with_pixels, const SlotOffsets &so) {
-        const int y = t / tiles_x;
-        const int x0 = (t - y * tiles_x) * TPX;
+        const int ty = t / tiles_x;
+        const int y = a.out_y0 + ty; // global row
+        const int x0 = (t - ty * tiles_x) * TPX;
         const int kc = min(KC, a.k_pad - k0);
         const int kn = min(kc, a.n_images - k0);
         const uint32_t px_addr = lds_base + uint32_t(pb) * (C::PX_DW * 4);
@@ -160,7 +162,7 @@ __global__ void __launch_bounds__(256, WGS)
                     const int g1 = min(g0 + 1, k0 + kn - 1);       // odd tail: the second half reloads the last image
                     const int ox = so.ox[j], oy = so.oy[j];         // this half-wave's image: g0 (h = 0) or g1 (h = 1)
                     const int g = h ? g1 : g0;
-                    const int sy = clampi(y + oy, 0, H - 1);
+                    const int sy = clampi(y + oy, 0, H - 1) - a.in_y0; // clamp in the full image, then index the held rows
                     const int sx = x0 + ox + 4 * r;
                     const bool inside = (sx >= 0) && (sx + 4 <= W) && (2 * q + 1 < kn || h == 0);
                     const bool all_inside = __builtin_amdgcn_ballot_w64(inside) == ~0ull;
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256, WGS)
                             if(2 * q + img >= kn)
                                 break;
                             const int oxi = __builtin_amdgcn_readlane(ox, img * 32), oyi = __builtin_amdgcn_readlane(oy, img * 32);
-                            const int syy = clampi(y + oyi, 0, H - 1);
+                            const int syy = clampi(y + oyi, 0, H - 1) - a.in_y0;
                             const uint32_t *row = grid32 + (size_t)(g0 + img) * plane_px + (size_t)syy * W;
 #pragma unroll
                             for(int s = 0; s < 2; s++)
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(256, WGS)
         else
         {
             // all-focus: the warp depends on the pixel's own focus value (src/kernels.cu:78-82): per-pixel gather
-            const uint8_t *map_plane = a.maps + (size_t)a.map_index * plane_px * 4;
+            const uint8_t *map_plane = a.maps + (size_t)a.map_index * (size_t)W * H * 4; // maps are whole-image planes
             const float f0 = decode_focus(map_plane, W, H, x0 + lane, y, a.focus, a.range);
             const float f1 = decode_focus(map_plane, W, H, x0 + 64 + lane, y, a.focus, a.range);
             for(int gi = wave; gi < kn; gi += C::NW)
@@ -201,9 +203,9 @@ __global__ void __launch_bounds__(256, WGS)
                 const lfi_float2 off = {c_offsets[2 * (k0 + gi)], c_offsets[2 * (k0 + gi) + 1]};
                 const uint32_t *plane = grid32 + (size_t)(k0 + gi) * plane_px;
                 const int sx0 = clampi(warp_float(x0 + lane, f0, off.x), 0, W - 1);
-                const int sy0 = clampi(warp_float(y, f0, off.y), 0, H - 1);
+                const int sy0 = clampi(warp_float(y, f0, off.y), 0, H - 1) - a.in_y0;
                 const int sx1 = clampi(warp_float(x0 + 64 + lane, f1, off.x), 0, W - 1);
-                const int sy1 = clampi(warp_float(y, f1, off.y), 0, H - 1);
+                const int sy1 = clampi(warp_float(y, f1, off.y), 0, H - 1) - a.in_y0;
                 dma4(plane + (size_t)sy0 * W + sx0, px_addr + uint32_t(gi) * 512u);
                 dma4(plane + (size_t)sy1 * W + sx1, px_addr + uint32_t(gi) * 512u + 256u);
             }
@@ -371,7 +373,7 @@ __global__ void __launch_bounds__(256, WGS)
         prev_stores = 0;
         if(k0 + KC >= a.k_pad)
         {
-            const int y = t / tiles_x;
+            const int y = t / tiles_x; // row inside the output window
             const int x0 = (t - y * tiles_x) * TPX;
             const int xw = x0 + wave * 32;
             const int vbase = a.v0 + pass * VPP;
@@ -388,8 +390,8 @@ __global__ void __launch_bounds__(256, WGS)
                         quantize_tile_rn(acc[m][0], acc[m][1], acc[m][2], rgba);
                     else
                         quantize_tile_packed(acc[m][0], acc[m][1], acc[m][2], rgba);
-                    uint32_t *ubase = reinterpret_cast<uint32_t *>(a.views) + (size_t)view_m * plane_px + (size_t)y * W + xw;
-                    const uint32_t lane_off = uint32_t(r) + uint32_t(4 * h) * uint32_t(plane_px);
+                    uint32_t *ubase = reinterpret_cast<uint32_t *>(a.views) + (size_t)view_m * oplane_px + (size_t)y * W + xw;
+                    const uint32_t lane_off = uint32_t(r) + uint32_t(4 * h) * uint32_t(oplane_px);
                     if(nvalid == 32 && xw + 32 <= W)
                     {
                         // full M-tile, full run: 16 unpredicated stores
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(256, WGS)
 #pragma unroll
                         for(int e = 0; e < 16; e++)
                         {
-                            uint32_t *out = ubase + (size_t)((e & 3) + 8 * (e >> 2)) * plane_px + lane_off;
+                            uint32_t *out = ubase + (size_t)((e & 3) + 8 * (e >> 2)) * oplane_px + lane_off;
                             if constexpr(NT_STORE)
                                 __builtin_nontemporal_store(rgba[e], out);
                             else
@@ -414,7 +416,7 @@ __global__ void __launch_bounds__(256, WGS)
                             if(vrow < nvalid) // wave-uniform; lane (r = 0, h = 0) is then always active, so the store is issued
                             {
                                 n_st++;
-                                uint32_t *out = ubase + (size_t)vrow * plane_px + lane_off;
+                                uint32_t *out = ubase + (size_t)vrow * oplane_px + lane_off;
                                 if(lane_x_ok && vrow + 4 * h < nvalid)
                                 {
                                     if constexpr(NT_STORE)

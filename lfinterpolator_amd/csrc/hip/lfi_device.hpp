@@ -36,7 +36,10 @@ struct KernelArgs
     const int32_t *__restrict__ focus_ids;  // [n_focus_ids]                        (focusMapIDs)
     float *__restrict__ prequant;           // optional [H][W][3] accumulators of view `prequant_view`
     int32_t prequant_view;
-    int32_t width, height;                  // constants[0..1]
+    int32_t width, height;                  // constants[0..1]: the FULL image size (clamping and parameters refer to it)
+    // Row window (spatial multi-GPU sharding): this context holds rows [in_y0, in_y0+in_rows) of every input plane and
+    // renders output rows [out_y0, out_y0+out_rows) into planes of out_rows rows.  Whole image: 0, height, 0, height.
+    int32_t in_y0, in_rows, out_y0, out_rows;
     int32_t n_images;                       // constants[5]
     int32_t k_pad;                          // n_images rounded up to 16
     int32_t v_pad;                          // views rounded up to 64

@@ -31,6 +31,7 @@ struct Variant
     void (*launch)(const lfi_ctx *, const KernelArgs &, bool all_focus);
     bool packed_epilogue; // TEN_WM: needs weights in [0,2) (×2^15 copy)
     bool prequant = false; // can dump pre-quantisation accumulators (the generic kernels only)
+    bool row_window = false; // honours a row window (the persistent kernels)
 };
 extern const Variant kTenVariants[];
 extern const Variant kStdVariants[];
@@ -46,6 +47,9 @@ struct lfi_ctx
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int cols = 0, rows = 0, n = 0, width = 0, height = 0;
+    // row window (lfi_set_row_window): input rows held / output rows rendered; the whole image by default
+    int in_y0 = 0, in_rows = 0, out_y0 = 0, out_rows = 0;
+    bool windowed = false;
     uint8_t *grid = nullptr;
     bool own_grid = false;
     size_t grid_bytes = 0;
@@ -97,9 +101,19 @@ int bind(lfi_ctx *ctx)
     return LFI_OK;
 }
 
-size_t plane_bytes(const lfi_ctx *c)
+size_t plane_bytes(const lfi_ctx *c) // a whole-image plane (focus maps; inputs and outputs without a row window)
 {
     return (size_t)c->width * c->height * 4;
+}
+
+size_t in_plane_bytes(const lfi_ctx *c)
+{
+    return (size_t)c->width * c->in_rows * 4;
+}
+
+size_t out_plane_bytes(const lfi_ctx *c)
+{
+    return (size_t)c->width * c->out_rows * 4;
 }
 
 KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
@@ -119,6 +133,10 @@ KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
     a.prequant_view = -1;
     a.width = c->width;
     a.height = c->height;
+    a.in_y0 = c->in_y0;
+    a.in_rows = c->in_rows;
+    a.out_y0 = c->out_y0;
+    a.out_rows = c->out_rows;
     a.n_images = c->n;
     a.k_pad = c->k_pad;
     a.v_pad = c->v_pad;
@@ -194,7 +212,7 @@ void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
     constexpr int TPX = 128, VPP = MT * 32;
     const int tiles_x = (a.width + TPX - 1) / TPX;
-    const int n_tiles = tiles_x * a.height;
+    const int n_tiles = tiles_x * a.out_rows;
     const int passes = (a.v1 - a.v0 + VPP - 1) / VPP;
     // persistent: WGS workgroups per CU (2 x 80 KB of LDS at KC = 64), each walks tiles j, j+G, j+2G ...
     const dim3 grid(std::min(n_tiles, WGS * cu_count_of(c))), block(256);
@@ -229,10 +247,10 @@ void launch_std_valu(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 
 // first entry = default ("auto")
 const Variant kTenVariants[] = {
-    {"persist_m2_nt", launch_persist<false, 2, true>, true},
-    {"persist_m2", launch_persist<false, 2, false>, true},
+    {"persist_m2_nt", launch_persist<false, 2, true>, true, false, true},
+    {"persist_m2", launch_persist<false, 2, false>, true, false, true},
     {"direct_p1m2", launch_ten_direct<1, 2>, false, true},
-    {"persist_m1", launch_persist<false, 1, true>, true},
+    {"persist_m1", launch_persist<false, 1, true>, true, false, true},
     {"lds_n1m2_w3", launch_ten_lds<1, 2, 4, 1, 64, 3>, true},
     {"lds_n1m1_w4", launch_ten_lds<1, 1, 4, 1, 64, 4>, true},
     {"lds_n2m1_w3", launch_ten_lds<2, 1, 2, 2, 64, 3>, true},
@@ -243,8 +261,8 @@ const Variant kTenVariants[] = {
     {"direct_p1m1", launch_ten_direct<1, 1>, false, true},
 };
 const Variant kStdVariants[] = {
-    {"persist_m2_nt", launch_persist<true, 2, true>, false},
-    {"persist_m1_nt", launch_persist<true, 1, true>, false},
+    {"persist_m2_nt", launch_persist<true, 2, true>, false, false, true},
+    {"persist_m1_nt", launch_persist<true, 1, true>, false, false, true},
     {"mfma_p1m2", launch_std_mfma<1, 2>, false, true}, {"mfma_p2m2", launch_std_mfma<2, 2>, false, true}, {"mfma_p2m1", launch_std_mfma<2, 1>, false, true},
     {"mfma_p4m1", launch_std_mfma<4, 1>, false, true}, {"valu", launch_std_valu, false, true},
 };
@@ -285,6 +303,15 @@ int cu_count_of(const lfi_ctx *c) { return c->cu_count; }
 
 int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
 {
+    if(c->windowed)
+    {
+        // a row window is honoured by the persistent fixed-focus kernels only
+        const bool ten = method == LFI_METHOD_TEN_WM;
+        const Variant &v = ten ? kTenVariants[c->ten_variant] : kStdVariants[c->std_variant];
+        if(all_focus || a.prequant || !v.row_window || (c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) ||
+           (ten && v.packed_epilogue && !c->weights_scalable))
+            return fail(c, LFI_EINVAL, "with a row window only fixed-focus renders with the default (persistent) kernels and weights in [0,2) are supported");
+    }
     if(method == LFI_METHOD_TEN_WM)
     {
         // the generic kernel (direct_p1m2) serves what the packed-epilogue kernels cannot: the per-batch rounding debug
@@ -449,12 +476,43 @@ int lfi_set_grid(lfi_ctx *ctx, int cols, int rows, int width, int height)
     ctx->n = cols * rows;
     ctx->width = width;
     ctx->height = height;
+    ctx->in_y0 = ctx->out_y0 = 0;
+    ctx->in_rows = ctx->out_rows = height;
+    ctx->windowed = false;
     ctx->grid_bytes = plane_bytes(ctx) * ctx->n;
     LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->grid), ctx->grid_bytes));
     ctx->own_grid = true;
     LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->maps), plane_bytes(ctx) * 2));
     LFI_HIP(ctx, hipMemsetAsync(ctx->maps, 0, plane_bytes(ctx) * 2, ctx->stream));
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LFI_OK;
+}
+
+int lfi_set_row_window(lfi_ctx *ctx, int out_y0, int out_y1, int in_y0, int in_y1)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->n)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(!(0 <= out_y0 && out_y0 < out_y1 && out_y1 <= ctx->height && 0 <= in_y0 && in_y0 < in_y1 && in_y1 <= ctx->height))
+        return fail(ctx, LFI_EINVAL, "row window outside the image");
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_params(ctx);
+    free_views(ctx);
+    if(ctx->own_grid && ctx->grid)
+        (void)hipFree(ctx->grid);
+    ctx->grid = nullptr;
+    ctx->own_grid = false;
+    ctx->in_y0 = in_y0;
+    ctx->in_rows = in_y1 - in_y0;
+    ctx->out_y0 = out_y0;
+    ctx->out_rows = out_y1 - out_y0;
+    ctx->windowed = !(in_y0 == 0 && in_y1 == ctx->height && out_y0 == 0 && out_y1 == ctx->height);
+    ctx->grid_bytes = in_plane_bytes(ctx) * ctx->n;
+    LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->grid), ctx->grid_bytes));
+    ctx->own_grid = true;
     return LFI_OK;
 }
 
@@ -468,8 +526,9 @@ int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_byte
         return fail(ctx, LFI_EINVAL, "bad image index, pointer or pitch");
     if(int rc = bind(ctx))
         return rc;
-    LFI_HIP(ctx, hipMemcpy2DAsync(ctx->grid + plane_bytes(ctx) * g, (size_t)ctx->width * 4, rgba, pitch_bytes,
-                                  (size_t)ctx->width * 4, ctx->height, hipMemcpyHostToDevice, ctx->stream));
+    // rgba addresses row 0 of the whole image; only the rows this context holds are copied
+    LFI_HIP(ctx, hipMemcpy2DAsync(ctx->grid + in_plane_bytes(ctx) * g, (size_t)ctx->width * 4, rgba + (size_t)ctx->in_y0 * pitch_bytes,
+                                  pitch_bytes, (size_t)ctx->width * 4, ctx->in_rows, hipMemcpyHostToDevice, ctx->stream));
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LFI_OK;
 }
@@ -480,8 +539,8 @@ int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes)
         return LFI_EINVAL;
     if(!ctx->n)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
-    if(!device_ptr || bytes < plane_bytes(ctx) * ctx->n)
-        return fail(ctx, LFI_EINVAL, "attached grid buffer is NULL or smaller than N*H*W*4 bytes");
+    if(!device_ptr || bytes < in_plane_bytes(ctx) * ctx->n)
+        return fail(ctx, LFI_EINVAL, "attached grid buffer is NULL or smaller than N*rows*W*4 bytes");
     if(reinterpret_cast<uintptr_t>(device_ptr) % 16)
         return fail(ctx, LFI_EINVAL, "attached grid buffer must be 16-byte aligned");
     if(int rc = bind(ctx))
@@ -501,7 +560,7 @@ int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes)
         return LFI_EINVAL;
     *out_ptr = ctx->grid;
     if(out_bytes)
-        *out_bytes = ctx->grid ? plane_bytes(ctx) * ctx->n : 0;
+        *out_bytes = ctx->grid ? in_plane_bytes(ctx) * ctx->n : 0;
     return LFI_OK;
 }
 
@@ -514,7 +573,7 @@ int lfi_fill_synthetic(lfi_ctx *ctx, uint32_t seed)
     if(int rc = bind(ctx))
         return rc;
     hipLaunchKernelGGL(lfi::fill_synthetic, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, ctx->n, ctx->width,
-                       ctx->height, seed);
+                       ctx->in_rows, ctx->in_y0, seed);
     LFI_HIP(ctx, hipGetLastError());
     return LFI_OK;
 }
@@ -538,6 +597,14 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
         return rc;
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
+    if(ctx->windowed)
+        for(int g = 0; g < ctx->n; g++)
+        {
+            const int oy = p->focused_offsets[g].y, H = ctx->height;
+            const int lo = std::min(std::max(ctx->out_y0 + oy, 0), H - 1), hi = std::min(std::max(ctx->out_y0 + ctx->out_rows - 1 + oy, 0), H - 1);
+            if(lo < ctx->in_y0 || hi >= ctx->in_y0 + ctx->in_rows)
+                return fail(ctx, LFI_EINVAL, "the input row window does not cover the rows image " + std::to_string(g) + " is sampled at");
+        }
     const int n = ctx->n, V = p->views;
     const int k_pad = (n + 15) / 16 * 16;
     // 64 spare rows: a view range may start anywhere, and a wave always reads whole 32-row tiles
@@ -603,10 +670,10 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     if(views_changed || !ctx->views)
     {
         const bool was_attached = ctx->views && !ctx->own_views;
-        if(!(was_attached && ctx->views_bytes >= plane_bytes(ctx) * V))
+        if(!(was_attached && ctx->views_bytes >= out_plane_bytes(ctx) * V))
         {
             free_views(ctx);
-            ctx->views_bytes = plane_bytes(ctx) * V;
+            ctx->views_bytes = out_plane_bytes(ctx) * V;
             LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->views), ctx->views_bytes));
             ctx->own_views = true;
         }
@@ -621,8 +688,8 @@ int lfi_attach_views(lfi_ctx *ctx, void *device_ptr, size_t bytes)
         return LFI_EINVAL;
     if(!ctx->have_params)
         return fail(ctx, LFI_EINVAL, "lfi_set_params has not been called");
-    if(!device_ptr || bytes < plane_bytes(ctx) * ctx->views_n)
-        return fail(ctx, LFI_EINVAL, "attached view buffer is NULL or smaller than V*H*W*4 bytes");
+    if(!device_ptr || bytes < out_plane_bytes(ctx) * ctx->views_n)
+        return fail(ctx, LFI_EINVAL, "attached view buffer is NULL or smaller than V*rows*W*4 bytes");
     if(reinterpret_cast<uintptr_t>(device_ptr) % 16)
         return fail(ctx, LFI_EINVAL, "attached view buffer must be 16-byte aligned");
     if(int rc = bind(ctx))
@@ -640,7 +707,7 @@ int lfi_views_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes)
         return LFI_EINVAL;
     *out_ptr = ctx->views;
     if(out_bytes)
-        *out_bytes = ctx->views ? plane_bytes(ctx) * ctx->views_n : 0;
+        *out_bytes = ctx->views ? out_plane_bytes(ctx) * ctx->views_n : 0;
     return LFI_OK;
 }
 
@@ -650,6 +717,8 @@ int lfi_focus_map(lfi_ctx *ctx)
         return LFI_EINVAL;
     if(!ctx->grid || !ctx->have_params)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid / lfi_set_params have not been called");
+    if(ctx->windowed)
+        return fail(ctx, LFI_EINVAL, "the focus map is not supported with a row window");
     if(ctx->n_focus_ids < 1)
         return fail(ctx, LFI_EINVAL, "no focus_map_ids in the parameters");
     if(!(ctx->range > 0.0f))
@@ -770,8 +839,9 @@ int lfi_download_view(lfi_ctx *ctx, int v, uint8_t *rgba, size_t pitch_bytes)
         return fail(ctx, LFI_EINVAL, "bad view index, pointer or pitch");
     if(int rc = bind(ctx))
         return rc;
-    LFI_HIP(ctx, hipMemcpy2DAsync(rgba, pitch_bytes, ctx->views + plane_bytes(ctx) * v, (size_t)ctx->width * 4,
-                                  (size_t)ctx->width * 4, ctx->height, hipMemcpyDeviceToHost, ctx->stream));
+    // rgba addresses row 0 of the whole view; the rows this context rendered are written at their place
+    LFI_HIP(ctx, hipMemcpy2DAsync(rgba + (size_t)ctx->out_y0 * pitch_bytes, pitch_bytes, ctx->views + out_plane_bytes(ctx) * v,
+                                  (size_t)ctx->width * 4, (size_t)ctx->width * 4, ctx->out_rows, hipMemcpyDeviceToHost, ctx->stream));
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LFI_OK;
 }
@@ -809,9 +879,9 @@ int lfi_download_quilt(lfi_ctx *ctx, int tiles_x, int tiles_y, int v0, uint8_t *
         for(int tx = 0; tx < tiles_x; tx++)
         {
             const int v = v0 + ty * tiles_x + tx;
-            uint8_t *dst = rgba + (size_t)ty * ctx->height * pitch_bytes + (size_t)tx * ctx->width * 4;
-            LFI_HIP(ctx, hipMemcpy2DAsync(dst, pitch_bytes, ctx->views + plane_bytes(ctx) * v, (size_t)ctx->width * 4,
-                                          (size_t)ctx->width * 4, ctx->height, hipMemcpyDeviceToHost, ctx->stream));
+            uint8_t *dst = rgba + ((size_t)ty * ctx->height + ctx->out_y0) * pitch_bytes + (size_t)tx * ctx->width * 4;
+            LFI_HIP(ctx, hipMemcpy2DAsync(dst, pitch_bytes, ctx->views + out_plane_bytes(ctx) * v, (size_t)ctx->width * 4,
+                                          (size_t)ctx->width * 4, ctx->out_rows, hipMemcpyDeviceToHost, ctx->stream));
         }
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LFI_OK;
@@ -932,6 +1002,8 @@ int lfi_download_coords(lfi_ctx *ctx, int g, int all_focus, int map_index, lfi_i
         return fail(ctx, LFI_EINVAL, "lfi_set_grid / lfi_set_params have not been called");
     if(g < 0 || g >= ctx->n || !out_hw || map_index < 0 || map_index > 1)
         return fail(ctx, LFI_EINVAL, "bad image index, map index or pointer");
+    if(ctx->windowed)
+        return fail(ctx, LFI_EINVAL, "coordinate dumps are not supported with a row window");
     if(int rc = bind(ctx))
         return rc;
     const size_t bytes = sizeof(lfi_int2) * (size_t)ctx->width * ctx->height;

@@ -33,3 +33,20 @@ def broadcast_grid(grid_tensor, src: int = 0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(grid_tensor, src=src)
     return grid_tensor
+
+
+# ---- row-band (spatial) sharding: each rank renders a band of rows of EVERY view and holds only the input rows the band's
+# warp reaches — per-GPU bytes shrink ≈1/G for inputs and outputs alike (view sharding re-reads the whole input on every rank)
+
+def row_band(height: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous, balanced split of the image rows."""
+    return view_range(height, world, rank)
+
+
+def input_rows(band: tuple[int, int], focused_offsets, height: int) -> tuple[int, int]:
+    """Rows [in_y0, in_y1) of the input images that output rows `band` sample: clamp(y + oy_g, 0, H-1) over all images g."""
+    import numpy as np
+    oy = np.asarray(focused_offsets)[:, 1].astype(np.int64)
+    lo = np.clip(band[0] + oy, 0, height - 1).min()
+    hi = np.clip(band[1] - 1 + oy, 0, height - 1).max()
+    return int(lo), int(hi) + 1

@@ -19,6 +19,31 @@ def test_view_range_partition(native):
         native.view_range(8, 2, 2)
 
 
+def test_row_band_input_rows(native, oracle_c):
+    """Row-band sharding: the bands tile the image and each band's input rows are exactly the rows its warp samples."""
+    cols = rows = 8
+    W, H = 64, 90
+    hp = native.build_params(cols, rows, W, H, "0,0,1,1", 0.23, 0.0, 3.0, 1.783, 4)
+    for world in (1, 2, 3, 8):
+        covered = 0
+        for rank in range(world):
+            band = native.row_band(H, world, rank)
+            in_rows = native.input_rows(band, hp.focused_offsets, H)
+            sampled = set()
+            for g in range(cols * rows):
+                for y in (band[0], band[1] - 1):
+                    sampled.add(int(np.clip(y + hp.focused_offsets[g, 1], 0, H - 1)))
+            assert in_rows == (min(sampled), max(sampled) + 1)
+            assert 0 <= in_rows[0] <= band[0] or in_rows[0] <= H - 1
+            covered += band[1] - band[0]
+        assert covered == H
+    # a band in the middle of a tall image needs only band + halo rows, far fewer than H
+    band = native.row_band(1080, 8, 3)
+    hp_big = native.build_params(8, 8, 1920, 1080, "0,0,1,1", 0.23, 0.0, 3.0, 1.783, 4)
+    lo, hi = native.input_rows(band, hp_big.focused_offsets, 1080)
+    assert hi - lo == (band[1] - band[0]) + 2 * 108 and hi - lo < 1080 // 2
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

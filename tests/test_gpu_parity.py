@@ -234,6 +234,58 @@ def test_view_range_sharding_is_exact(gpu):
     ctx.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_band_sharding_matches_full_render(world, gpu, oracle_c):
+    """every rank renders a band of rows from the input rows its warp reaches; the bands together are the
+    full render, byte for byte, and each rank holds far fewer input rows than the image has."""
+    cols = rows = 8
+    W, H, V = 200, 96, 64
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.1, 0.0, 3.0, 1.783, V)
+    lf = oracle_c.synthetic_lf(64, W, H, SEED)
+    full = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    for method in ("STD", "TEN_WM"):
+        full.render(method)
+        full.sync()
+        want = full.download_views()
+        got = np.zeros_like(want)
+        held = []
+        for rank in range(world):
+            band = gpu.row_band(H, world, rank)
+            in_rows = gpu.input_rows(band, hp.focused_offsets, H)
+            held.append(in_rows[1] - in_rows[0])
+            ctx = gpu.Context(0)
+            ctx.set_grid(cols, rows, W, H)
+            ctx.set_row_window(band[0], band[1], in_rows[0], in_rows[1])
+            if rank % 2:
+                ctx.fill_synthetic(SEED)     # device-side generation of just the held rows
+            else:
+                ctx.upload_grid(lf)          # whole-image host pointers, only the held rows are copied
+            ctx.set_params(hp)
+            assert ctx.grid_device_ptr()[1] == 64 * (in_rows[1] - in_rows[0]) * W * 4
+            ctx.render(method)
+            ctx.sync()
+            part = ctx.download_views()
+            assert (part[:, :band[0]] == 0).all() and (part[:, band[1]:] == 0).all()
+            got |= part
+            if rank == 0:
+                with pytest.raises(gpu.LfiError, match="row window"):
+                    ctx.render(method, all_focus=True)
+                with pytest.raises(gpu.LfiError, match="row window"):
+                    ctx.focus_map()
+            ctx.close()
+        assert (got == want).all(), method
+        assert max(held) < H
+    if True:
+        # an input window that misses sampled rows is refused
+        ctx = gpu.Context(0)
+        ctx.set_grid(cols, rows, W, H)
+        ctx.set_row_window(10, 20, 10, 20)
+        with pytest.raises(gpu.LfiError, match="does not cover"):
+            ctx.set_params(hp)
+        ctx.close()
+    full.close()
+
+
 def test_quilt_download(gpu):
     cols = rows = 3
     W, H, V = 40, 12, 10
