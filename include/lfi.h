@@ -117,6 +117,12 @@ int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_byte
 /* Use caller-owned device memory ([N][H][W][4] u8, ≥ N*H*W*4 bytes) for the input planes instead of the context's
  * own allocation — lets the caller fill it (e.g. an RCCL broadcast into a tensor it owns).  Call after lfi_set_grid. */
 int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes);
+/* Single-process multi-GPU: copy the input planes of ctxs[root] into every other context's planes with ONE RCCL broadcast over
+ * xGMI (ncclCommInitAll + ncclBroadcast; RCCL is loaded on first use) — the light field then lives on every GPU and rendering
+ * needs no further collective.  All contexts must sit on distinct devices and describe the same grid and row
+ * window.  n == 1 is a no-op.  Synchronous.  (One process per GPU instead: broadcast the attached buffers with your own
+ * communicator, as bench.py does through torch.distributed.) */
+int lfi_broadcast_grid(lfi_ctx *const *ctxs, int n, int root);
 /* device pointer / size of the input planes currently in use */
 int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes);
 /* fill the input planes on the device with the synthetic light field of SURVEY.md §8(d):

@@ -19,7 +19,7 @@ METHODS = {"STD": LFI_METHOD_STD, "TEN_WM": LFI_METHOD_TEN_WM, "FOCUS": LFI_KERN
 # every symbol include/lfi.h declares
 ABI_SYMBOLS = [
     "lfi_create", "lfi_destroy", "lfi_last_error", "lfi_abi_version", "lfi_device_count", "lfi_set_grid", "lfi_set_row_window",
-    "lfi_upload_image", "lfi_attach_grid", "lfi_grid_device_ptr", "lfi_fill_synthetic", "lfi_set_params",
+    "lfi_upload_image", "lfi_attach_grid", "lfi_broadcast_grid", "lfi_grid_device_ptr", "lfi_fill_synthetic", "lfi_set_params",
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
     "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
@@ -72,6 +72,7 @@ def load_hip_library() -> C.CDLL:
         "lfi_set_row_window": (i, [vp, i, i, i, i]),
         "lfi_upload_image": (i, [vp, i, vp, sz]),
         "lfi_attach_grid": (i, [vp, vp, sz]),
+        "lfi_broadcast_grid": (i, [C.POINTER(vp), i, i]),
         "lfi_grid_device_ptr": (i, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "lfi_fill_synthetic": (i, [vp, C.c_uint32]),
         "lfi_set_params": (i, [vp, C.POINTER(_Params)]),
@@ -106,6 +107,15 @@ def load_hip_library() -> C.CDLL:
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def broadcast_grid(contexts, root: int = 0) -> None:
+    """lfi_broadcast_grid over a list of Context objects (single process, one context per GPU, RCCL)."""
+    lib = load_hip_library()
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    rc = lib.lfi_broadcast_grid(arr, len(contexts), root)
+    if rc != 0:
+        raise LfiError(f"lfi_broadcast_grid failed ({rc}): {lib.lfi_last_error(contexts[root]._h).decode()}")
 
 
 class Context:

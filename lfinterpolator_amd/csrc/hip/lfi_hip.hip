@@ -4,6 +4,8 @@
 // above the ABI (lfinterpolator_amd/csrc/host).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -370,6 +372,42 @@ void free_grid(lfi_ctx *c)
 
 } // namespace
 
+// RCCL through dlopen: the library has no link-time dependency on it and single-GPU users never load it
+namespace {
+struct Rccl
+{
+    typedef void *comm_t;
+    int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+
+const Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if(!h)
+            h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if(!h)
+            return x;
+        x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(h, "ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(dlsym(h, "ncclBroadcast"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        x.ok = x.CommInitAll && x.CommDestroy && x.GroupStart && x.GroupEnd && x.Broadcast && x.GetErrorString;
+        return x;
+    }();
+    return r;
+}
+} // namespace
+
 extern "C" {
 
 int lfi_abi_version(void)
@@ -552,6 +590,63 @@ int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes)
     ctx->own_grid = false;
     ctx->grid_bytes = bytes;
     return LFI_OK;
+}
+
+int lfi_broadcast_grid(lfi_ctx *const *ctxs, int n, int root)
+{
+    if(!ctxs || n < 1 || root < 0 || root >= n)
+        return LFI_EINVAL;
+    for(int i = 0; i < n; i++)
+        if(!ctxs[i])
+            return LFI_EINVAL;
+    lfi_ctx *r0 = ctxs[root];
+    if(!r0->grid)
+        return fail(r0, LFI_EINVAL, "lfi_set_grid has not been called on the root context");
+    if(n == 1)
+        return LFI_OK;
+    std::vector<int> devs(n);
+    for(int i = 0; i < n; i++)
+    {
+        lfi_ctx *c = ctxs[i];
+        if(!c->grid || c->n != r0->n || c->width != r0->width || c->height != r0->height || c->in_y0 != r0->in_y0 || c->in_rows != r0->in_rows)
+            return fail(r0, LFI_EINVAL, "all contexts of a broadcast must describe the same grid and row window");
+        devs[i] = c->device;
+        for(int j = 0; j < i; j++)
+            if(devs[j] == devs[i])
+                return fail(r0, LFI_EINVAL, "the contexts of a broadcast must sit on distinct devices");
+    }
+    const Rccl &nc = rccl();
+    if(!nc.ok)
+        return fail(r0, LFI_EHIP, "librccl.so could not be loaded");
+    std::vector<Rccl::comm_t> comms(n, nullptr);
+    int rc = nc.CommInitAll(comms.data(), n, devs.data());
+    if(rc != 0)
+        return fail(r0, LFI_EHIP, std::string("ncclCommInitAll: ") + nc.GetErrorString(rc));
+    const size_t bytes = in_plane_bytes(r0) * r0->n;
+    constexpr int NCCL_UINT8 = 1;
+    int status = LFI_OK;
+    rc = nc.GroupStart();
+    for(int i = 0; i < n && rc == 0; i++)
+    {
+        if(hipSetDevice(ctxs[i]->device) != hipSuccess)
+        {
+            rc = -1;
+            break;
+        }
+        rc = nc.Broadcast(r0->grid, ctxs[i]->grid, bytes, NCCL_UINT8, root, comms[i], ctxs[i]->stream);
+    }
+    const int rc_end = nc.GroupEnd();
+    if(rc != 0 || rc_end != 0)
+        status = fail(r0, LFI_EHIP, std::string("ncclBroadcast: ") + (rc > 0 ? nc.GetErrorString(rc) : rc_end ? nc.GetErrorString(rc_end) : "hipSetDevice failed"));
+    for(int i = 0; i < n; i++)
+    {
+        (void)hipSetDevice(ctxs[i]->device);
+        if(hipStreamSynchronize(ctxs[i]->stream) != hipSuccess && status == LFI_OK)
+            status = fail(r0, LFI_EHIP, "hipStreamSynchronize after the broadcast failed");
+    }
+    for(int i = 0; i < n; i++)
+        (void)nc.CommDestroy(comms[i]);
+    return status;
 }
 
 int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes)

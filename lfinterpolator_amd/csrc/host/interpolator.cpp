@@ -4,6 +4,7 @@
 #include "interpolator.h"
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <filesystem>
 #include <future>
@@ -34,14 +35,55 @@ Interpolator::Interpolator(lfi::IVec2 inColsRows, lfi::IVec2 inResolution, uint3
 
 Interpolator::~Interpolator()
 {
+    for(size_t i = 1; i < contexts.size(); i++)
+        lfi_destroy(contexts[i]);
     if(context)
         lfi_destroy(context);
 }
 
 void Interpolator::check(int status) const
 {
+    check(status, context);
+}
+
+void Interpolator::check(int status, lfi_ctx *where) const
+{
     if(status != LFI_OK)
-        throw std::runtime_error(std::string("GPU error: ") + lfi_last_error(context));
+        throw std::runtime_error(std::string("GPU error: ") + lfi_last_error(where));
+}
+
+// One context per GPU: the grid is broadcast once from the GPU it was loaded on, then every GPU gets its contiguous range of
+// views (its own rows of the weight matrix; offsets are the same everywhere) — no further communication.
+void Interpolator::shardOverGpus(const lfi::HostParams &params)
+{
+    if(contexts.empty())
+    {
+        contexts.push_back(context);
+        for(int g = 1; g < gpuCount; g++)
+        {
+            lfi_ctx *extra = nullptr;
+            check(lfi_create(device + g, &extra), nullptr);
+            contexts.push_back(extra);
+            check(lfi_set_grid(extra, colsRows.x, colsRows.y, resolution.x, resolution.y), extra);
+        }
+        if(gpuCount > 1)
+        {
+            std::cout << "Broadcasting the light field to " << gpuCount << " GPUs..." << std::endl;
+            check(lfi_broadcast_grid(contexts.data(), gpuCount, 0));
+        }
+    }
+    viewStart.assign(gpuCount + 1, 0);
+    for(int g = 0; g < gpuCount; g++)
+        viewStart[g + 1] = viewStart[g] + viewCount / gpuCount + (g < viewCount % gpuCount ? 1 : 0);
+    const size_t n = params.offsets.size();
+    for(int g = 0; g < gpuCount; g++)
+    {
+        lfi::HostParams part = params;
+        part.views = viewStart[g + 1] - viewStart[g];
+        part.weights.assign(params.weights.begin() + viewStart[g] * n, params.weights.begin() + viewStart[g + 1] * n);
+        const lfi_params abi = part.abi();
+        check(lfi_set_params(contexts[g], &abi), contexts[g]);
+    }
 }
 
 void Interpolator::init()
@@ -85,25 +127,59 @@ void Interpolator::interpolate(std::string outputPath, std::string trajectory, f
     lfi::HostParams params = parameterizer.build(trajectory, focus, range, effect, aspect, viewCount);
     if(referenceMapQuirk)
         params.flags |= LFI_FLAG_REFERENCE_MAP_QUIRK;
-    const lfi_params abi = params.abi();
-    check(lfi_set_params(context, &abi));
+    if(gpuCount < 1 || gpuCount > viewCount)
+        throw std::runtime_error("The number of GPUs has to be between 1 and the number of views!");
+    shardOverGpus(params);
 
     const int allFocus = inRange > 0;
     if(allFocus)
     {
         std::cout << "Estimating focus map..." << std::endl;
-        check(lfi_focus_map(context));
+        for(lfi_ctx *c : contexts)
+            check(lfi_focus_map(c), c);
     }
 
     std::cout << "Rendering views..." << std::endl;
     std::cout << "Elapsed time: " << std::endl;
-    lfi_bench_stats stats{};
-    // the reference's mean includes its cold first launch; one warm-up launch is excluded here
-    check(lfi_benchmark(context, methodID, allFocus, 0, viewCount, 1, static_cast<int>(kernelBenchmarkRuns), &stats));
-    averageTime = stats.mean_ms;
-    std::cout << "Average time of " << std::to_string(kernelBenchmarkRuns) << " runs: " << stats.mean_ms << " ms" << std::endl;
-    const double seconds = stats.median_ms / 1000.0;
-    std::cout << "Median " << stats.median_ms << " ms, min " << stats.min_ms << " ms: " << viewCount / seconds << " views/s, "
+    double medianMs;
+    if(gpuCount == 1)
+    {
+        lfi_bench_stats stats{};
+        // the reference's mean includes its cold first launch; one warm-up launch is excluded here
+        check(lfi_benchmark(context, methodID, allFocus, 0, viewCount, 1, static_cast<int>(kernelBenchmarkRuns), &stats));
+        averageTime = stats.mean_ms;
+        medianMs = stats.median_ms;
+        std::cout << "Average time of " << std::to_string(kernelBenchmarkRuns) << " runs: " << stats.mean_ms << " ms" << std::endl;
+        std::cout << "Median " << stats.median_ms << " ms, min " << stats.min_ms << " ms";
+    }
+    else
+    {
+        // all GPUs launch their view ranges concurrently; a run ends when the slowest GPU has finished
+        const auto launchAll = [&] {
+            for(int g = 0; g < gpuCount; g++)
+                check(lfi_render(contexts[g], methodID, allFocus, 0, viewStart[g + 1] - viewStart[g]), contexts[g]);
+            for(lfi_ctx *c : contexts)
+                check(lfi_sync(c), c);
+        };
+        launchAll();
+        std::vector<double> times;
+        for(size_t i = 0; i < kernelBenchmarkRuns; i++)
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            launchAll();
+            times.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        double sum = 0;
+        for(double t : times)
+            sum += t;
+        averageTime = static_cast<float>(sum / times.size());
+        std::sort(times.begin(), times.end());
+        medianMs = times[times.size() / 2];
+        std::cout << "Average time of " << std::to_string(kernelBenchmarkRuns) << " runs on " << gpuCount << " GPUs: " << averageTime << " ms" << std::endl;
+        std::cout << "Median " << medianMs << " ms (host clock around all GPUs)";
+    }
+    const double seconds = medianMs / 1000.0;
+    std::cout << ": " << viewCount / seconds << " views/s, "
               << static_cast<double>(viewCount) * resolution.x * resolution.y / seconds / 1e9 << " Gpix/s" << std::endl;
     storeResults(outputPath);
 }
@@ -154,7 +230,12 @@ void Interpolator::storeResults(std::string path)
             check(lfi_download_map(context, i - viewCount, data, pitch));
         }
         else
-            check(lfi_download_view(context, i, data, pitch));
+        {
+            int g = 0;
+            while(g + 1 < gpuCount && i >= viewStart[g + 1])
+                g++;
+            check(lfi_download_view(contexts[g], i - viewStart[g], data, pitch), contexts[g]);
+        }
         jobs.push_back(std::async(std::launch::async, [&, slot, data, fileName] {
             try
             {
@@ -187,6 +268,8 @@ void Interpolator::storeResults(std::string path)
         std::cout << "Storing quilt..." << std::endl;
         const size_t quiltPitch = pitch * quiltTiles.x;
         std::vector<uint8_t> quilt(quiltPitch * resolution.y * quiltTiles.y);
+        if(gpuCount > 1)
+            throw std::runtime_error("The quilt output is available on a single GPU only!");
         check(lfi_download_quilt(context, quiltTiles.x, quiltTiles.y, 0, quilt.data(), quiltPitch));
         lfi::writePng((std::filesystem::path(path) / "quilt.png").string(), resolution.x * quiltTiles.x, resolution.y * quiltTiles.y,
                       static_cast<int>(channels), quilt.data(), quiltPitch);

@@ -26,6 +26,8 @@ class Interpolator
         // also write quilt.png: the views as one image of cols × rows tiles (what scripts/viewsToQuilt.sh montages, 5×9 there)
         void setQuilt(lfi::IVec2 tiles) { quiltTiles = tiles; }
         float lastAverageTime() const { return averageTime; }
+        // render on GPUs 0 … count-1 of this node: views are split into contiguous ranges, the grid is broadcast once (RCCL)
+        void setGpuCount(int count) { gpuCount = count; }
 
         // synthetic cols×rows grid of width×height images instead of a directory
         Interpolator(lfi::IVec2 colsRows, lfi::IVec2 resolution, uint32_t seed, int device = 0);
@@ -38,6 +40,9 @@ class Interpolator
         bool referenceMapQuirk{false};
         lfi::IVec2 quiltTiles{0, 0};
         lfi_ctx *context{nullptr};
+        int gpuCount{1};
+        std::vector<lfi_ctx *> contexts; // one per GPU; contexts[0] == context
+        std::vector<int> viewStart;      // first view of each GPU's range (size gpuCount + 1)
         float focus{0};
         float range{0};
         float averageTime{0};
@@ -49,4 +54,6 @@ class Interpolator
         void loadGPUData();
         void storeResults(std::string path);
         void check(int status) const;
+        void check(int status, lfi_ctx *where) const;
+        void shardOverGpus(const lfi::HostParams &params);
 };

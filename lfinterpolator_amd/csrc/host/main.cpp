@@ -35,6 +35,7 @@ int main(int argc, char **argv)
                           "-n - number of views rendered along the trajectory (default=64)\n"
                           "-b - number of timed kernel launches (default=100)\n"
                           "-d - GPU index (default=0)\n"
+                          "-g - number of GPUs: the views are split over GPUs d … d+g-1, the input grid is broadcast once (default=1)\n"
                           "-q - also store quilt.png: the first cols*rows views as cols,rows tiles (e.g. 5,9 for a Looking Glass quilt)\n"
                           "--synthetic cols,rows,width,height[,seed] - use a generated light field instead of -i\n"
                         };
@@ -79,6 +80,8 @@ int main(int argc, char **argv)
         }
         if(args["-n"])
             interpolator->setViewCount(static_cast<int>(args["-n"]));
+        if(args["-g"])
+            interpolator->setGpuCount(static_cast<int>(args["-g"]));
         if(args["-b"])
             interpolator->setBenchmarkRuns(static_cast<size_t>(static_cast<int>(args["-b"])));
         if(args["-q"])

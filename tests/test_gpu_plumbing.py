@@ -81,6 +81,24 @@ def test_two_contexts_are_independent(gpu, oracle_c):
     b.close()
 
 
+def test_single_process_broadcast(gpu):
+    """lfi_broadcast_grid: a no-op for one context; contexts on one device are refused before RCCL is touched
+    (two distinct GPUs are needed for a real broadcast, which only the multi-GPU node has)."""
+    from lfinterpolator_amd.abi import broadcast_grid
+    a, b = gpu.Context(0), gpu.Context(0)
+    for c in (a, b):
+        c.set_grid(2, 2, 32, 8)
+    a.fill_synthetic(3)
+    broadcast_grid([a])
+    with pytest.raises(gpu.LfiError, match="distinct devices"):
+        broadcast_grid([a, b], root=0)
+    b.set_grid(2, 2, 32, 16)
+    with pytest.raises(gpu.LfiError, match="same grid"):
+        broadcast_grid([a, b], root=0)
+    a.close()
+    b.close()
+
+
 def test_bench_json_contract(gpu):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                           "--prewarm-ms", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
