@@ -54,7 +54,7 @@ if not args.no_parity:
     parity(8, 8, 130, 9, 64, rng=0.2)
     parity(15, 15, 48, 20, 8, focus=3.0, effect=7.0)
 
-cfgs = {2: (8, 8, 1920, 1080, 64), 3: (15, 15, 1920, 1080, 45), 4: (8, 8, 3840, 2160, 32), 41: (8, 8, 3840, 2160, 256), 5: (15, 15, 3840, 2160, 64)}
+cfgs = {2: (8, 8, 1920, 1080, 64), 3: (15, 15, 1920, 1080, 45), 4: (8, 8, 3840, 2160, 32), 41: (8, 8, 3840, 2160, 256), 31: (15, 15, 1920, 1080, 1), 21: (8, 8, 1920, 1080, 1), 5: (15, 15, 3840, 2160, 64)}
 cols, rows, W, H, V = cfgs[args.config]
 ctx = L.Context(0)
 ctx.set_grid(cols, rows, W, H); ctx.fill_synthetic(0x1F1F); ctx.sync()
