@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,7 +19,7 @@
 #include "blend_ten.hpp"
 #include "blend_ten_lds.hpp"
 #include "blend_ten_persist.hpp"
-#include "focus_map.hpp"
+#include "focus_factored.hpp"
 #include "lfi_device.hpp"
 
 using lfi::KernelArgs;
@@ -73,6 +74,9 @@ struct lfi_ctx
     int radius[2] = {1, 1};
     uint32_t flags = 0;
     float *prequant = nullptr;
+    std::vector<lfi_float2> h_focus_offsets; // offsets of the focus_map_ids images (host copy: sizes the padded planes)
+    void *focus_ws = nullptr; // workspace of the factored focus-map estimate (plan, E, K), allocated on first use
+    size_t focus_ws_bytes = 0;
     int ten_variant = 0, std_variant = 0, focus_variant = 0;
     std::string err;
 };
@@ -368,6 +372,100 @@ void free_grid(lfi_ctx *c)
     if(c->prequant)
         (void)hipFree(c->prequant);
     c->prequant = nullptr;
+    if(c->focus_ws)
+        (void)hipFree(c->focus_ws);
+    c->focus_ws = nullptr;
+    c->focus_ws_bytes = 0;
+}
+
+// the factored estimate (focus_factored.hpp): carve the workspace, then plan → pad → E → exact keys → pick.
+// Returns LFI_OK with *done = false when the padded planes would be unreasonably large (the caller takes another variant).
+int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
+{
+    *done = false;
+    const int W = ctx->width, H = ctx->height, rx = ctx->radius[0], ry = ctx->radius[1];
+    lfi::FocusWork w{};
+    w.We_p = (W + 2 * rx + 255) / 256 * 256;
+    w.He_p = (H + 2 * ry + 3) / 4 * 4;
+    // largest |shift| any candidate gives any sampled image: candidates are monotone in i, so the ends bound them
+    const float step = ctx->range / 31.0f;
+    const double fmax = std::max(std::fabs((double)ctx->focus), std::fabs((double)std::fmaf(step, 31.0f, ctx->focus)));
+    double ox = 0, oy = 0;
+    for(const lfi_float2 &o : ctx->h_focus_offsets)
+    {
+        ox = std::max(ox, std::fabs((double)o.x));
+        oy = std::max(oy, std::fabs((double)o.y));
+    }
+    if(!(fmax * ox < 1e6 && fmax * oy < 1e6))
+        return LFI_OK;
+    const int Sx = (int)std::ceil(fmax * ox) + 1, Sy = (int)std::ceil(fmax * oy) + 1; // ≥ |floor(δ)| and ≥ |floor(δ)+1|
+    w.Px = Sx + rx;
+    w.Py = Sy + ry;
+    w.Wp = (w.Px + std::max(W + Sx + rx, w.We_p - rx + Sx) + 3) / 4 * 4;
+    w.Hp = w.Py + std::max(H + Sy + ry, w.He_p - ry + Sy);
+    const size_t pad_bytes = sizeof(uint32_t) * (size_t)ctx->n_focus_ids * w.Hp * w.Wp;
+    if(pad_bytes > ((size_t)16 << 30))
+        return LFI_OK;
+    size_t at = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t here = at;
+        at += (bytes + 255) / 256 * 256;
+        return here;
+    };
+    const size_t o_shifts = carve(sizeof(int32_t) * 4 * lfi::FOCUS_STEPS * lfi::FOCUS_MAX_IDS);
+    const size_t o_badx = carve(sizeof(uint32_t) * W), o_bady = carve(sizeof(uint32_t) * H);
+    const size_t o_cols = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * W), o_rows = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * H);
+    const size_t o_ncols = carve(sizeof(int32_t) * lfi::FOCUS_STEPS), o_nrows = carve(sizeof(int32_t) * lfi::FOCUS_STEPS);
+    const size_t o_prefix = carve(sizeof(uint32_t) * (2 * lfi::FOCUS_STEPS + 1));
+    const size_t o_E = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * (size_t)w.He_p * w.We_p);
+    const size_t o_K = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * (size_t)H * W);
+    const size_t o_deltas = carve(sizeof(int64_t) * lfi::FOCUS_STEPS * lfi::FOCUS_MAX_IDS);
+    const size_t o_pad = carve(pad_bytes);
+    if(ctx->focus_ws_bytes != at)
+    {
+        if(ctx->focus_ws)
+            (void)hipFree(ctx->focus_ws);
+        ctx->focus_ws = nullptr;
+        ctx->focus_ws_bytes = 0;
+        LFI_HIP(ctx, hipMalloc(&ctx->focus_ws, at));
+        ctx->focus_ws_bytes = at;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->focus_ws);
+    w.shifts = reinterpret_cast<int32_t *>(base + o_shifts);
+    w.badx = reinterpret_cast<uint32_t *>(base + o_badx);
+    w.bady = reinterpret_cast<uint32_t *>(base + o_bady);
+    w.cols = reinterpret_cast<uint16_t *>(base + o_cols);
+    w.rows = reinterpret_cast<uint16_t *>(base + o_rows);
+    w.ncols = reinterpret_cast<int32_t *>(base + o_ncols);
+    w.nrows = reinterpret_cast<int32_t *>(base + o_nrows);
+    w.prefix = reinterpret_cast<uint32_t *>(base + o_prefix);
+    w.E = reinterpret_cast<uint16_t *>(base + o_E);
+    w.K = reinterpret_cast<uint16_t *>(base + o_K);
+    w.deltas = reinterpret_cast<int64_t *>(base + o_deltas);
+    w.pad = reinterpret_cast<uint32_t *>(base + o_pad);
+    hipStream_t st = ctx->stream;
+    LFI_HIP(ctx, hipMemsetAsync(w.badx, 0, o_cols - o_badx, st)); // badx and bady are adjacent
+    hipLaunchKernelGGL(lfi::focus_plan_shifts, dim3(1), dim3(1024), 0, st, a, w);
+    hipLaunchKernelGGL(lfi::focus_plan_flags, dim3((std::max(W, H) + 255) / 256, lfi::FOCUS_STEPS, 2), dim3(256), 0, st, a, w);
+    hipLaunchKernelGGL(lfi::focus_plan_lists, dim3(lfi::FOCUS_STEPS, 2), dim3(64), 0, st, a, w);
+    hipLaunchKernelGGL(lfi::focus_plan_prefix, dim3(1), dim3(1), 0, st, a, w);
+    hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, ctx->n_focus_ids), dim3(64), 0, st, a, w);
+    const uint32_t ntiles = uint32_t(w.We_p / 256) * uint32_t(w.He_p / 4);
+    const char *cpw_env = getenv("LFI_FOCUS_CPW");
+    const int cpw = cpw_env ? atoi(cpw_env) : 4;
+    if(cpw == 1)
+        hipLaunchKernelGGL(lfi::focus_range<1>, dim3(ntiles * 32), dim3(256), 0, st, a, w, ntiles * 32);
+    else if(cpw == 2)
+        hipLaunchKernelGGL(lfi::focus_range<2>, dim3(ntiles * 16), dim3(256), 0, st, a, w, ntiles * 16);
+    else if(cpw == 8)
+        hipLaunchKernelGGL(lfi::focus_range<8>, dim3(ntiles * 4), dim3(256), 0, st, a, w, ntiles * 4);
+    else
+        hipLaunchKernelGGL(lfi::focus_range<4>, dim3(ntiles * 8), dim3(256), 0, st, a, w, ntiles * 8);
+    hipLaunchKernelGGL(lfi::focus_exact, dim3(ctx->cu_count * 4), dim3(256), 0, st, a, w);
+    hipLaunchKernelGGL(lfi::focus_pick, pixel_grid(ctx), dim3(256), 0, st, a, w);
+    LFI_HIP(ctx, hipGetLastError());
+    *done = true;
+    return LFI_OK;
 }
 
 } // namespace
@@ -756,6 +854,9 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     ctx->v_pad = v_pad;
     ctx->views_n = V;
     ctx->n_focus_ids = p->n_focus_ids;
+    ctx->h_focus_offsets.clear();
+    for(int k = 0; k < p->n_focus_ids; k++)
+        ctx->h_focus_offsets.push_back(p->offsets[p->focus_map_ids[k]]);
     ctx->focus = p->focus;
     ctx->range = p->range;
     ctx->radius[0] = std::max(p->block_radius[0], 1);
@@ -823,11 +924,18 @@ int lfi_focus_map(lfi_ctx *ctx)
     const KernelArgs a = make_args(ctx, 0, ctx->views_n, LFI_METHOD_STD);
     // the LDS-staged kernel needs its window (128 + 2·radius_x + slack pixels) to fit a 256-pixel LDS row
     const bool lds_fits = 128 + 2 * ctx->radius[0] + 2 * lfi::FOCUS_LDS_SLACK <= lfi::FOCUS_LDS_ROW;
-    if(ctx->focus_variant == 0 && lds_fits) // "lds" (default)
+    // "factored" (default): W and H must fit the 16-bit column / row lists
+    bool done = false;
+    if(ctx->focus_variant == 0 && ctx->width <= 65535 && ctx->height <= 65535)
+        if(int rc = launch_focus_factored(ctx, a, &done))
+            return rc;
+    if(done)
+        ;
+    else if(ctx->focus_variant <= 1 && lds_fits) // "lds"
         hipLaunchKernelGGL(lfi::focus_estimate_lds, dim3((ctx->width + 127) / 128, ctx->height), dim3(64), 0, ctx->stream, a);
-    else if(ctx->focus_variant == 3) // "plain": one pixel per lane, float min/max exactly as the reference writes it
+    else if(ctx->focus_variant == 4) // "plain": one pixel per lane, float min/max exactly as the reference writes it
         hipLaunchKernelGGL(lfi::focus_estimate, pixel_grid(ctx), dim3(256), 0, ctx->stream, a);
-    else if(ctx->focus_variant == 2) // "packed_p4"
+    else if(ctx->focus_variant == 3) // "packed_p4"
         hipLaunchKernelGGL((lfi::focus_estimate_packed<4, 2>), dim3((ctx->width + 255) / 256, ctx->height), dim3(64), 0, ctx->stream, a);
     else // "packed_p2" (also the fallback of "lds" for very large radii)
         hipLaunchKernelGGL((lfi::focus_estimate_packed<2, 4>), dim3((ctx->width + 127) / 128, ctx->height), dim3(64), 0, ctx->stream, a);
@@ -1034,7 +1142,7 @@ const char *lfi_list_variants(int method)
     if(method == LFI_METHOD_STD)
         return std_.c_str();
     if(method == LFI_KERNEL_FOCUS_ESTIMATE)
-        return "lds,packed_p2,packed_p4,plain";
+        return "factored,lds,packed_p2,packed_p4,plain";
     return "";
 }
 
@@ -1073,13 +1181,13 @@ int lfi_set_variant(lfi_ctx *ctx, int method, const char *name)
     }
     else if(method == LFI_KERNEL_FOCUS_ESTIMATE)
     {
-        static const char *const names[] = {"lds", "packed_p2", "packed_p4", "plain"};
+        static const char *const names[] = {"factored", "lds", "packed_p2", "packed_p4", "plain"};
         if(is_auto)
         {
             ctx->focus_variant = 0;
             return LFI_OK;
         }
-        for(int i = 0; i < 4; i++)
+        for(int i = 0; i < 5; i++)
             if(std::strcmp(name, names[i]) == 0)
             {
                 ctx->focus_variant = i;
