@@ -172,14 +172,24 @@ __global__ void focus_plan_prefix(const KernelArgs a, const FocusWork w)
 // pixels), back to back, so all but the first are L1 hits.  Work order: candidate group fastest, tiles row-major, one
 // contiguous run of the sequence per XCD (all 32 candidates of a tile meet in one L2).
 template <int CPW>
-__global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const FocusWork w, const uint32_t nblocks)
+__global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const FocusWork w, const uint32_t nblocks, const int striped)
 {
     constexpr int GROUPS = FOCUS_STEPS / CPW;
-    const uint32_t work = xcd_contiguous(blockIdx.x, nblocks);
-    const int i0 = int(work % GROUPS) * CPW;
-    const uint32_t tile = work / GROUPS;
-    const int tiles_x = w.We_p >> 8;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t tiles_x = uint32_t(w.We_p) >> 8, tiles_y = uint32_t(w.He_p) >> 2;
+    uint32_t tx, ty, group;
+    if(striped)
+    {
+        if(!stripe_map(blockIdx.x, tiles_x, tiles_y, GROUPS, tx, ty, group))
+            return;
+    }
+    else
+    {
+        const uint32_t work = xcd_contiguous(blockIdx.x, nblocks);
+        group = work % GROUPS;
+        tx = (work / GROUPS) % tiles_x;
+        ty = (work / GROUPS) / tiles_x;
+    }
+    const int i0 = int(group) * CPW;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ey = ty * 4 + wave;              // row in E
@@ -357,43 +367,121 @@ __global__ void __launch_bounds__(256) focus_exact(const KernelArgs a, const Foc
     }
 }
 
-// dispersion per candidate = nine samples of E (or the exact key where flagged); first strict minimum → map 0
-__global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const FocusWork w)
+// dispersion per candidate = nine samples of E (or the exact key where flagged); first strict minimum → map 0.
+// Blocks of 4 rows × 64·PPL pixels, a lane owns PPL ∈ {1, 2} adjacent pixels; PPL = 2 reads both pixels' samples with one
+// dword load and needs an even radius_x (the E columns x + rx ± rx of an even x are then dword aligned) — the reference always
+// produces one (src/interpolator.cu:143-146).  Vertical stripes per XCD (stripe_map) keep the ±r rows of all 32 candidates in
+// one L2 (row bands per XCD for images narrower than 8 blocks).  Every sample is scalar plane base + per-lane tap offset.
+template <int PPL>
+__global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const FocusWork w, const uint32_t nblocks, const int striped)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int W = a.width, H = a.height;
-    if(x >= W || y >= H)
+    const uint32_t blocks_x = uint32_t(W + 64 * PPL - 1) / uint32_t(64 * PPL), blocks_y = uint32_t(H + 3) / 4u;
+    uint32_t bx, by, unused;
+    if(striped)
+    {
+        if(!stripe_map(blockIdx.x, blocks_x, blocks_y, 1u, bx, by, unused))
+            return;
+    }
+    else
+    {
+        const uint32_t block = xcd_contiguous(blockIdx.x, nblocks);
+        bx = block % blocks_x;
+        by = block / blocks_x;
+    }
+    const int x = (int(bx) * 64 + int(threadIdx.x & 63)) * PPL;
+    const int y = int(by) * 4 + int(threadIdx.x >> 6);
+    if(y >= H) // wave-uniform
         return;
     const int rx = a.radius_x, ry = a.radius_y;
-    const uint32_t flagged = w.badx[x] | w.bady[y];
-    uint32_t best_key = 0xffffffffu;
-    int best_i = 0;
-    const size_t plane = (size_t)w.He_p * w.We_p;
-    const uint16_t *centre = w.E + (size_t)(y + ry) * w.We_p + (x + rx);
-#pragma unroll 4
-    for(int i = 0; i < FOCUS_STEPS; i++)
+    // lanes past the right edge compute pixel 0 and store nothing; the second pixel of a lane at x = W − 1 (odd W) reads
+    // one element past a row of badx / E / K, inside the workspace, and is not stored either
+    const int xs = x < W ? x : 0;
+    uint32_t flagged[PPL];
+#pragma unroll
+    for(int j = 0; j < PPL; j++)
+        flagged[j] = w.badx[xs + j] | w.bady[y];
+    bool any = false;
+#pragma unroll
+    for(int j = 0; j < PPL; j++)
+        any = any || flagged[j] != 0u;
+    const bool wave_flagged = __builtin_amdgcn_ballot_w64(any) != 0ull;
+
+    uint32_t tap[9]; // byte offsets of the nine samples inside a candidate's plane of E
+#pragma unroll
+    for(int ty = 0; ty < 3; ty++)
+#pragma unroll
+        for(int tx = 0; tx < 3; tx++)
+            tap[ty * 3 + tx] = uint32_t((y + ty * ry) * w.We_p + (xs + tx * rx)) * 2u;
+    const size_t plane_bytes = (size_t)w.He_p * w.We_p * 2;
+    const uint8_t *plane = reinterpret_cast<const uint8_t *>(w.E);
+    const uint16_t *exact = w.K + (size_t)y * W + xs;
+
+    uint32_t best_key[PPL];
+    int best_i[PPL];
+#pragma unroll
+    for(int j = 0; j < PPL; j++)
     {
-        const uint16_t *e = centre + (size_t)i * plane;
-        uint32_t sum = 0;
-#pragma unroll
-        for(int ty = -1; ty <= 1; ty++)
-#pragma unroll
-            for(int tx = -1; tx <= 1; tx++)
-                sum += e[ty * ry * w.We_p + tx * rx];
-        uint32_t key = sum >= 16u ? (sum & ~15u) : sum;
-        if((flagged >> i) & 1u)
-            key = w.K[((size_t)i * H + y) * W + x];
-        if(key < best_key) // MinDispersion::add (src/kernels.cu:225-231): strict <
-        {
-            best_key = key;
-            best_i = i;
-        }
+        best_key[j] = 0xffffffffu;
+        best_i[j] = 0;
     }
-    const float best_f = focus_candidate(a, best_i);
-    const float normalized = __fdiv_rn(best_f - a.focus, a.range);
-    const uint32_t m = static_cast<uint32_t>(roundf(normalized * 255.0f)) & 0xffu;
-    reinterpret_cast<uint32_t *>(a.maps)[(size_t)y * W + x] = m | (m << 8) | (m << 16) | 0xff000000u;
+    auto candidate = [&](const int i, const bool with_exact) {
+        uint32_t sum[PPL];
+        if constexpr(PPL == 2)
+        {
+            u16x2 acc = as_u16x2(0u); // 9 · 4081 < 65536 per half
+#pragma unroll
+            for(int t = 0; t < 9; t++)
+                acc += as_u16x2(*reinterpret_cast<const uint32_t *>(plane + tap[t]));
+            sum[0] = as_u32(acc) & 0xffffu;
+            sum[1] = as_u32(acc) >> 16;
+        }
+        else
+        {
+            sum[0] = 0;
+#pragma unroll
+            for(int t = 0; t < 9; t++)
+                sum[0] += *reinterpret_cast<const uint16_t *>(plane + tap[t]);
+        }
+#pragma unroll
+        for(int j = 0; j < PPL; j++)
+        {
+            uint32_t key = sum[j] >= 16u ? (sum[j] & ~15u) : sum[j];
+            if(with_exact)
+            {
+                const uint32_t k_exact = exact[j]; // unconditional: flagged lanes are rare, a divergent load costs more
+                key = ((flagged[j] >> i) & 1u) ? k_exact : key;
+            }
+            if(key < best_key[j]) // MinDispersion::add (src/kernels.cu:225-231): strict <
+            {
+                best_key[j] = key;
+                best_i[j] = i;
+            }
+        }
+        plane += plane_bytes;
+        exact += (size_t)H * W;
+    };
+    if(wave_flagged)
+    {
+#pragma unroll 2
+        for(int i = 0; i < FOCUS_STEPS; i++)
+            candidate(i, true);
+    }
+    else
+    {
+#pragma unroll 4
+        for(int i = 0; i < FOCUS_STEPS; i++)
+            candidate(i, false);
+    }
+#pragma unroll
+    for(int j = 0; j < PPL; j++)
+        if(x + j < W)
+        {
+            const float best_f = focus_candidate(a, best_i[j]);
+            const float normalized = __fdiv_rn(best_f - a.focus, a.range);
+            const uint32_t m = static_cast<uint32_t>(roundf(normalized * 255.0f)) & 0xffu;
+            reinterpret_cast<uint32_t *>(a.maps)[(size_t)y * W + x + j] = m | (m << 8) | (m << 16) | 0xff000000u;
+        }
 }
 
 } // namespace lfi

@@ -91,6 +91,29 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t nblocks)
     return xcd * q + min(xcd, rem) + idx;
 }
 
+// Vertical stripes: XCD x owns tile columns [x·tiles_x/8, (x+1)·tiles_x/8) and walks them row by row, `inner` work items per
+// tile back to back.  For kernels whose tiles re-read a band of rows above and below: the band × stripe width × planes is
+// what has to stay in one L2, instead of band × image width.  Launch 8·stripe_blocks_per_xcd(...) blocks; returns false
+// for the surplus blocks of the narrower stripes.  Needs tiles_x ≥ 8 (use xcd_contiguous otherwise).
+__host__ __device__ __forceinline__ uint32_t stripe_blocks_per_xcd(uint32_t tiles_x, uint32_t tiles_y, uint32_t inner)
+{
+    return ((tiles_x + 7u) / 8u) * tiles_y * inner;
+}
+
+__device__ __forceinline__ bool stripe_map(uint32_t b, uint32_t tiles_x, uint32_t tiles_y, uint32_t inner, uint32_t &tx,
+                                           uint32_t &ty, uint32_t &in)
+{
+    const uint32_t xcd = b & 7u, idx = b >> 3;
+    const uint32_t x0 = tiles_x * xcd / 8u, x1 = tiles_x * (xcd + 1u) / 8u, nx = x1 - x0;
+    if(idx >= nx * tiles_y * inner)
+        return false;
+    in = idx % inner;
+    const uint32_t t = idx / inner;
+    tx = x0 + t % nx;
+    ty = t / nx;
+    return true;
+}
+
 __device__ __forceinline__ uint32_t mix32(uint32_t x)
 {
     x ^= x >> 16;

@@ -450,19 +450,28 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     hipLaunchKernelGGL(lfi::focus_plan_lists, dim3(lfi::FOCUS_STEPS, 2), dim3(64), 0, st, a, w);
     hipLaunchKernelGGL(lfi::focus_plan_prefix, dim3(1), dim3(1), 0, st, a, w);
     hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, ctx->n_focus_ids), dim3(64), 0, st, a, w);
-    const uint32_t ntiles = uint32_t(w.We_p / 256) * uint32_t(w.He_p / 4);
-    const char *cpw_env = getenv("LFI_FOCUS_CPW");
-    const int cpw = cpw_env ? atoi(cpw_env) : 4;
-    if(cpw == 1)
-        hipLaunchKernelGGL(lfi::focus_range<1>, dim3(ntiles * 32), dim3(256), 0, st, a, w, ntiles * 32);
-    else if(cpw == 2)
-        hipLaunchKernelGGL(lfi::focus_range<2>, dim3(ntiles * 16), dim3(256), 0, st, a, w, ntiles * 16);
-    else if(cpw == 8)
-        hipLaunchKernelGGL(lfi::focus_range<8>, dim3(ntiles * 4), dim3(256), 0, st, a, w, ntiles * 4);
-    else
-        hipLaunchKernelGGL(lfi::focus_range<4>, dim3(ntiles * 8), dim3(256), 0, st, a, w, ntiles * 8);
+    const uint32_t tiles_x = uint32_t(w.We_p / 256), tiles_y = uint32_t(w.He_p / 4);
+    const char *stripe_env = getenv("LFI_FOCUS_STRIPES");
+    const bool allow_stripes = !stripe_env || atoi(stripe_env) != 0;
+    {
+        constexpr int CPW = 4, GROUPS = lfi::FOCUS_STEPS / CPW;
+        const int striped = allow_stripes && tiles_x >= 8;
+        const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(tiles_x, tiles_y, GROUPS) : tiles_x * tiles_y * GROUPS;
+        hipLaunchKernelGGL(lfi::focus_range<CPW>, dim3(nblocks), dim3(256), 0, st, a, w, nblocks, striped);
+    }
     hipLaunchKernelGGL(lfi::focus_exact, dim3(ctx->cu_count * 4), dim3(256), 0, st, a, w);
-    hipLaunchKernelGGL(lfi::focus_pick, pixel_grid(ctx), dim3(256), 0, st, a, w);
+    {
+        // two pixels per lane need dword-aligned sample pairs: even radius_x (the reference's is), and an even K pitch
+        const char *ppl_env = getenv("LFI_FOCUS_PICK_PPL");
+        const int ppl = (rx % 2 == 0 && W >= 2 && !(ppl_env && atoi(ppl_env) == 1)) ? 2 : 1;
+        const uint32_t bx = uint32_t((W + 64 * ppl - 1) / (64 * ppl)), by = uint32_t((H + 3) / 4);
+        const int striped = allow_stripes && bx >= 8;
+        const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(bx, by, 1u) : bx * by;
+        if(ppl == 2)
+            hipLaunchKernelGGL(lfi::focus_pick<2>, dim3(nblocks), dim3(256), 0, st, a, w, nblocks, striped);
+        else
+            hipLaunchKernelGGL(lfi::focus_pick<1>, dim3(nblocks), dim3(256), 0, st, a, w, nblocks, striped);
+    }
     LFI_HIP(ctx, hipGetLastError());
     *done = true;
     return LFI_OK;
