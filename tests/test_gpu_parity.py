@@ -392,3 +392,30 @@ def test_focus_map_wide_rows(shape, gpu, oracle_c):
         assert (ctx2.download_map(0) == want_black).all(), variant
     ctx.close()
     ctx2.close()
+
+
+@pytest.mark.parametrize("radius", [None, (3, 1), (5, 2)], ids=["radius_ref", "radius_3x1", "radius_5x2"])
+def test_focus_map_realistic_geometry(radius, gpu, oracle_c):
+    """The factored estimate (per-candidate range image + exact path for flagged columns / rows) at a size where most pixels
+    take the factored path and the flagged bands are real bands: shifts of tens of pixels in both directions, several block
+    rows per XCD stripe.  Odd radii take the one-pixel-per-lane pick kernel.  Every variant must give the oracle's bytes."""
+    cols, rows, W, H = 8, 8, 600, 300
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.22, 0.17, 7.0, 1.783, 4)
+    if radius is not None:
+        hp.block_radius = np.array(radius, np.int32)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, 33)
+    lf = (lf // 32 * 32).astype(np.uint8)
+    lf[:, :40, :70, :3] = 0      # an all-black corner: FLT_MIN taps next to ordinary ones
+    lf[..., 3] = 255
+    ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    want0 = oracle_c.focus_estimate(lf, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, threads=8)
+    assert len(np.unique(want0)) > 8
+    for variant in ("factored", "lds"):
+        ctx.set_variant("FOCUS", variant)
+        ctx.focus_map()
+        ctx.sync()
+        got = ctx.download_map(0)
+        assert (got == want0).all(), (variant, int((got != want0).sum()))
+        assert (ctx.download_map(1) == oracle_c.focus_filter(want0, hp.block_radius)).all(), variant
+    ctx.close()
+
