@@ -12,17 +12,22 @@
 // Exactness: the shortcut is used for (pixel, candidate) only where it is PROVEN identical.  focus_plan_flags evaluates,
 // for every column x (row y), candidate and view, the reference's own coordinate arithmetic and compares the three CLAMPED
 // tap coordinates with the ones the uniform shift gives; any difference (truncation toward zero left of / above the image,
-// or a float rounding of fma(f, offset, x) across an integer) flags (x, i) / (y, i).  Flagged pairs — bands of ≈r columns /
-// rows per view with a negative shift, a few % of all pairs — are evaluated tap by tap by focus_exact, a persistent kernel over
-// compact lists of flagged columns and rows, into K; focus_pick takes K instead of the factored sum wherever a flag is set.
+// or a float rounding of fma(f, offset, x) across an integer) flags (x, i) / (y, i) — bands of ≈r columns / rows per view
+// with a negative shift, ≈6 % of all pairs.  The coordinates are separable, so a pair flagged on ONE axis still factors
+// along the other:
+//   row y flagged, column not:  the tap rows are whatever the reference computes for (y, view), the tap columns are
+//       uniform shifts → three lines E'(i, y, ty)(qx) (focus_lines_rows), nine samples of those (focus_line_keys → K);
+//   column x flagged, row not:  three lines E''(i, x, tx)(qy) (focus_lines_cols), likewise;
+//   both flagged (or more flagged rows / columns than the line buffers hold): tap by tap, focus_exact → K.
+// focus_pick takes K instead of the factored sum wherever a flag is set.
 // The integer key (16·S + k, see focus_map.hpp) is the same as in the other variants, so results are bit-identical.
 //
 // Clamp-to-edge is taken out of the hot loops: focus_pad copies the ≤32 sampled images into planes padded by the largest
-// shift + r on every side (edge pixels replicated), so every sample of focus_range and focus_exact is an unclamped load at
-// scalar base + lane offset.
+// shift + r on every side (edge pixels replicated), so every sample is an unclamped load at scalar base + lane offset.
 //
-// Passes (all on the context's stream):  plan_shifts → plan_flags → plan_lists → plan_prefix, focus_pad → focus_range (E) →
-// focus_exact (K) → focus_pick (map 0) → focus_filter (map 1).
+// Passes (all on the context's stream):  plan_shifts → plan_flags → plan_lists → plan_prefix, focus_pad → focus_range (E),
+// focus_flagged = {focus_lines_rows (Er), focus_lines_cols (Ec), focus_exact (K)} → focus_line_keys (K) → focus_pick (map 0) →
+// focus_filter (map 1).
 #pragma once
 
 #include "focus_map.hpp"
@@ -41,7 +46,12 @@ struct FocusWork
     uint16_t *rows;     // [32][H]
     int32_t *ncols;     // [32]
     int32_t *nrows;     // [32]
-    uint32_t *prefix;   // [33] prefix sums of nrows
+    uint32_t *prefix;   // [3][33] prefix sums over the candidates of nrows, of ncols and of ceil(ncols/64) (column chunks)
+    uint32_t *rowbase;  // [H]  line slot of (row y, candidate i) = rowbase[y] + popcount(bady[y] & ((1 << i) − 1)):
+    uint32_t *colbase;  // [W]  exclusive prefix sums of popcount(bady / badx)
+    uint16_t *Er;       // [R_cap][3][We_p]      E'(slot, ty)(qx): row lines of the flagged-row slots below R_cap
+    uint16_t *Ec;       // [3][He_p][C_cap]      E''(tx)(qy)(slot): column lines of the flagged-column slots below C_cap
+    int32_t R_cap, C_cap;
     uint16_t *E;        // [32][He_p][We_p]  16·range + (FLT_MIN tap ? 1 : 0) over the extended image
     uint16_t *K;        // [32][H][W]        exact keys of flagged (pixel, candidate) pairs
     int32_t We_p, He_p; // pitches of E: W + 2rx rounded up to 256, H + 2ry rounded up to 4
@@ -134,37 +144,155 @@ __global__ void __launch_bounds__(256) focus_plan_flags(const KernelArgs a, cons
         atomicOr((axis ? w.bady : w.badx) + c, 1u << i);
 }
 
-// grid (32 candidates, 2 axes), one wave each: ordered compaction of the flagged columns / rows
+// line slot of a flagged (row or column c, candidate i) pair
+__device__ __forceinline__ uint32_t line_slot(const uint32_t base_c, const uint32_t bad_c, const int i)
+{
+    return base_c + uint32_t(__builtin_popcount(bad_c & ((1u << i) - 1u)));
+}
+
+// grid (32 candidates, 2 axes), one wave each: ordered compaction of the flagged columns / rows; the wave of candidate 0
+// also scans the per-coordinate flag counts into rowbase / colbase
 __global__ void __launch_bounds__(64) focus_plan_lists(const KernelArgs a, const FocusWork w)
 {
     const int i = blockIdx.x, axis = blockIdx.y, lane = threadIdx.x;
     const int L = axis ? a.height : a.width;
     const uint32_t *bad = axis ? w.bady : w.badx;
     uint16_t *list = (axis ? w.rows : w.cols) + (size_t)i * L;
+    uint32_t *base = axis ? w.rowbase : w.colbase;
     int count = 0;
+    uint32_t running = 0;
     for(int c0 = 0; c0 < L; c0 += 64)
     {
         const int c = c0 + lane;
-        const bool flagged = c < L && ((bad[c] >> i) & 1u);
+        const uint32_t bits = c < L ? bad[c] : 0u;
+        const bool flagged = (bits >> i) & 1u;
         const uint64_t m = __builtin_amdgcn_ballot_w64(flagged);
         if(flagged)
             list[count + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = static_cast<uint16_t>(c);
         count += __builtin_popcountll(m);
+        if(i == 0)
+        {
+            uint32_t incl = uint32_t(__builtin_popcount(bits)); // inclusive scan over the wave
+#pragma unroll
+            for(int d = 1; d < 64; d <<= 1)
+            {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                incl += lane >= d ? up : 0u;
+            }
+            if(c < L)
+                base[c] = running + incl - uint32_t(__builtin_popcount(bits));
+            running += __shfl(incl, 63, 64);
+        }
     }
     if(lane == 0)
         (axis ? w.nrows : w.ncols)[i] = count;
 }
 
-// one thread: prefix sums of the flagged-row counts (focus_exact walks the flagged rows of all candidates as one sequence)
+// one thread: the three prefix tables (the line and exact kernels walk all candidates' lists as one sequence)
 __global__ void focus_plan_prefix(const KernelArgs a, const FocusWork w)
 {
-    uint32_t sum = 0;
+    uint32_t rows = 0, cols = 0, chunks = 0;
     for(int i = 0; i < FOCUS_STEPS; i++)
     {
-        w.prefix[i] = sum;
-        sum += uint32_t(w.nrows[i]);
+        w.prefix[i] = rows;
+        w.prefix[33 + i] = cols;
+        w.prefix[66 + i] = chunks;
+        rows += uint32_t(w.nrows[i]);
+        cols += uint32_t(w.ncols[i]);
+        chunks += uint32_t(w.ncols[i] + 63) / 64u;
     }
-    w.prefix[FOCUS_STEPS] = sum;
+    w.prefix[32] = rows;
+    w.prefix[65] = cols;
+    w.prefix[98] = chunks;
+}
+
+// running per-channel min / max of FOUR consecutive pixels of a lane (two u16 pairs per channel) and the E encoding
+struct RangeAcc4
+{
+    u16x2 lo[2][3], hi[2][3];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for(int p = 0; p < 2; p++)
+#pragma unroll
+            for(int ch = 0; ch < 3; ch++)
+            {
+                lo[p][ch] = as_u16x2(0x00ff00ffu);
+                hi[p][ch] = as_u16x2(0u);
+            }
+    }
+    __device__ __forceinline__ void add(const u32x4 v)
+    {
+        const uint32_t px[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for(int p = 0; p < 2; p++)
+        {
+            const u16x2 cr = channel_pair<0>(px[2 * p], px[2 * p + 1]);
+            const u16x2 cg = channel_pair<1>(px[2 * p], px[2 * p + 1]);
+            const u16x2 cb = channel_pair<2>(px[2 * p], px[2 * p + 1]);
+            lo[p][0] = __builtin_elementwise_min(lo[p][0], cr);
+            hi[p][0] = __builtin_elementwise_max(hi[p][0], cr);
+            lo[p][1] = __builtin_elementwise_min(lo[p][1], cg);
+            hi[p][1] = __builtin_elementwise_max(hi[p][1], cg);
+            lo[p][2] = __builtin_elementwise_min(lo[p][2], cb);
+            hi[p][2] = __builtin_elementwise_max(hi[p][2], cb);
+        }
+    }
+    // four u16: 16·range + (FLT_MIN tap ? 1 : 0), see focus_map.hpp
+    __device__ __forceinline__ u32x2 encode() const
+    {
+        u32x2 out;
+#pragma unroll
+        for(int p = 0; p < 2; p++)
+        {
+            const u16x2 d0 = hi[p][0] - lo[p][0], d1 = hi[p][1] - lo[p][1], d2 = hi[p][2] - lo[p][2];
+            const u16x2 dmax = __builtin_elementwise_max(__builtin_elementwise_max(d0, d1), d2);
+            const u16x2 hmin = __builtin_elementwise_min(__builtin_elementwise_min(hi[p][0], hi[p][1]), hi[p][2]);
+            // FLT_MIN tap: range 0 and an all-zero channel
+            const u16x2 nz = __builtin_elementwise_min(as_u16x2(as_u32(dmax) | as_u32(hmin)), as_u16x2(0x00010001u));
+            const uint32_t e = (as_u32(dmax) << 4) + (0x00010001u - as_u32(nz)); // per half: 16·range ≤ 4080, no carry
+            if(p == 0)
+                out.x = e;
+            else
+                out.y = e;
+        }
+        return out;
+    }
+};
+
+// the same for ONE pixel per lane: (R, G) as a u16 pair, and B
+struct RangeAcc1
+{
+    u16x2 lo_rg, hi_rg, lo_b, hi_b;
+    __device__ __forceinline__ void init()
+    {
+        lo_rg = lo_b = as_u16x2(0x00ff00ffu);
+        hi_rg = hi_b = as_u16x2(0u);
+    }
+    __device__ __forceinline__ void add(const uint32_t px)
+    {
+        const u16x2 rg = as_u16x2(__builtin_amdgcn_perm(0u, px, 0x0c010c00u));
+        const u16x2 b = as_u16x2(__builtin_amdgcn_perm(0u, px, 0x0c020c02u));
+        lo_rg = __builtin_elementwise_min(lo_rg, rg);
+        hi_rg = __builtin_elementwise_max(hi_rg, rg);
+        lo_b = __builtin_elementwise_min(lo_b, b);
+        hi_b = __builtin_elementwise_max(hi_b, b);
+    }
+    __device__ __forceinline__ void result(uint32_t &range, uint32_t &flt_min_tap) const
+    {
+        const uint32_t d_rg = as_u32(hi_rg - lo_rg), d_b = as_u32(hi_b - lo_b) & 0xffffu;
+        range = max(max(d_rg & 0xffffu, d_rg >> 16), d_b);
+        const uint32_t h_rg = as_u32(hi_rg);
+        const uint32_t hmin = min(min(h_rg & 0xffffu, h_rg >> 16), as_u32(hi_b) & 0xffffu);
+        flt_min_tap = (range | hmin) == 0u ? 1u : 0u;
+    }
+};
+
+// walk a 33-entry prefix table forward: segment of a non-decreasing sequence of element indices (uniform)
+__device__ __forceinline__ void prefix_walk(const focus_const_u32_ptr prefix, const uint32_t e, int &seg)
+{
+    while(e >= prefix[seg + 1])
+        seg++;
 }
 
 // E_i(q): one workgroup = 256 extended columns × 4 extended rows (one row per wave) of CPW consecutive candidates; a lane
@@ -200,66 +328,199 @@ __global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const Foc
     const uint8_t *wave_base = reinterpret_cast<const uint8_t *>(w.pad) + ((size_t)(qy + w.Py) * w.Wp + (size_t)(qx_wave + w.Px)) * 4;
     const uint32_t lane_off = 16u * lane;
 
-    u16x2 lo[CPW][2][3], hi[CPW][2][3]; // [candidate][pixel pair][channel]
+    RangeAcc4 acc[CPW];
 #pragma unroll
     for(int c = 0; c < CPW; c++)
-#pragma unroll
-        for(int p = 0; p < 2; p++)
-#pragma unroll
-            for(int ch = 0; ch < 3; ch++)
-            {
-                lo[c][p][ch] = as_u16x2(0x00ff00ffu);
-                hi[c][p][ch] = as_u16x2(0u);
-            }
+        acc[c].init();
     const int n_ids = a.n_focus_ids;
     for(int k = 0; k < n_ids; k++)
     {
-        uint32_t px[CPW][4];
+        u32x4 px[CPW];
 #pragma unroll
         for(int c = 0; c < CPW; c++)
-        {
-            const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(wave_base + deltas[c * FOCUS_MAX_IDS + k] + lane_off);
-            px[c][0] = v.x;
-            px[c][1] = v.y;
-            px[c][2] = v.z;
-            px[c][3] = v.w;
-        }
+            px[c] = *reinterpret_cast<const u32x4_a4 *>(wave_base + deltas[c * FOCUS_MAX_IDS + k] + lane_off);
 #pragma unroll
         for(int c = 0; c < CPW; c++)
-#pragma unroll
-            for(int p = 0; p < 2; p++)
-            {
-                const u16x2 cr = channel_pair<0>(px[c][2 * p], px[c][2 * p + 1]);
-                const u16x2 cg = channel_pair<1>(px[c][2 * p], px[c][2 * p + 1]);
-                const u16x2 cb = channel_pair<2>(px[c][2 * p], px[c][2 * p + 1]);
-                lo[c][p][0] = __builtin_elementwise_min(lo[c][p][0], cr);
-                hi[c][p][0] = __builtin_elementwise_max(hi[c][p][0], cr);
-                lo[c][p][1] = __builtin_elementwise_min(lo[c][p][1], cg);
-                hi[c][p][1] = __builtin_elementwise_max(hi[c][p][1], cg);
-                lo[c][p][2] = __builtin_elementwise_min(lo[c][p][2], cb);
-                hi[c][p][2] = __builtin_elementwise_max(hi[c][p][2], cb);
-            }
+            acc[c].add(px[c]);
     }
 #pragma unroll
     for(int c = 0; c < CPW; c++)
     {
-        u32x2 out;
-#pragma unroll
-        for(int p = 0; p < 2; p++)
-        {
-            const u16x2 d0 = hi[c][p][0] - lo[c][p][0], d1 = hi[c][p][1] - lo[c][p][1], d2 = hi[c][p][2] - lo[c][p][2];
-            const u16x2 dmax = __builtin_elementwise_max(__builtin_elementwise_max(d0, d1), d2);
-            const u16x2 hmin = __builtin_elementwise_min(__builtin_elementwise_min(hi[c][p][0], hi[c][p][1]), hi[c][p][2]);
-            // FLT_MIN tap (focus_map.hpp): range 0 and an all-zero channel
-            const u16x2 nz = __builtin_elementwise_min(as_u16x2(as_u32(dmax) | as_u32(hmin)), as_u16x2(0x00010001u));
-            const uint32_t e = (as_u32(dmax) << 4) + (0x00010001u - as_u32(nz)); // per half: 16·range ≤ 4080, no carry
-            if(p == 0)
-                out.x = e;
-            else
-                out.y = e;
-        }
         uint16_t *dst = w.E + ((size_t)(i0 + c) * w.He_p + ey) * w.We_p + tx * 256 + 4 * lane;
-        *reinterpret_cast<u32x2 *>(dst) = out;
+        *reinterpret_cast<u32x2 *>(dst) = acc[c].encode();
+    }
+}
+
+// 64-bit readlane (lane index uniform)
+__device__ __forceinline__ uint64_t readlane64(const uint64_t v, const int lane)
+{
+    const uint32_t lo = __builtin_amdgcn_readlane(uint32_t(v), lane), hi = __builtin_amdgcn_readlane(uint32_t(v >> 32), lane);
+    return (uint64_t(hi) << 32) | lo;
+}
+
+// E'(slot, ty)(qx) for the flagged rows: like focus_range, but the source row of view k is the one the reference's
+// arithmetic gives for (row y, view k) plus (ty − 1)·ry.  Persistent.  XCD x (blocks b ≡ x mod 8) takes the 256-column tiles
+// ≡ x mod 8; its waves stride over (row, tile, candidate) — neighbouring rows and candidates read almost the same
+// source lines, which therefore meet in one L2.  The three ty lines are computed
+// together.  Per-view parameters live in lane k's registers (no scalar loads in the view loop); the samples of view k + 1
+// are in flight while view k is reduced.
+__device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const FocusWork &w, const uint32_t block, const uint32_t blocks)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t xcd = block & 7u;
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane((block >> 3) * 4 + (threadIdx.x >> 6));
+    const uint32_t n_waves = (blocks >> 3) * 4; // blocks is a multiple of 8
+    const uint32_t tiles_x = uint32_t(w.We_p) >> 8;
+    const uint32_t my_tiles = tiles_x > xcd ? (tiles_x - xcd + 7u) / 8u : 0u;
+    const int n_ids = a.n_focus_ids;
+    const int kk = lane < n_ids ? lane : 0;
+    const float offy_l = a.offsets[a.focus_ids[kk]].y;
+    const uint8_t *pad = reinterpret_cast<const uint8_t *>(w.pad) + 16u * lane;
+    const size_t tap_stride = (size_t)a.radius_y * w.Wp * 4;
+    for(uint32_t u = wave_id; u < uint32_t(a.height) * my_tiles * FOCUS_STEPS; u += n_waves)
+    {
+        // (row, tile of this XCD, candidate), candidate fastest: most units are unflagged and cost one uniform load
+        const int i = int(u % FOCUS_STEPS);
+        const uint32_t tile = xcd + 8u * ((u / FOCUS_STEPS) % my_tiles);
+        const int y = int(u / (FOCUS_STEPS * my_tiles));
+        const uint32_t flags = __builtin_amdgcn_readfirstlane(w.bady[y]);
+        if(((flags >> i) & 1u) == 0u)
+            continue;
+        {
+            const uint32_t slot = line_slot(__builtin_amdgcn_readfirstlane(w.rowbase[y]), flags, i);
+            if(slot >= uint32_t(w.R_cap))
+                continue; // focus_exact (B)
+            const float f = focus_candidate(a, i);
+            // lane k: byte offset of view k's ty = 0 sample of this tile's first column
+            const int sx_l = w.shifts[4 * (i * FOCUS_MAX_IDS + kk)];
+            const int row_l = warp_float(y, f, offy_l) - a.radius_y + w.Py;
+            const uint64_t off_l = (((uint64_t)kk * w.Hp + row_l) * w.Wp + uint64_t(int(tile) * 256 - a.radius_x + w.Px + sx_l)) * 4u;
+            RangeAcc4 acc[3];
+#pragma unroll
+            for(int t = 0; t < 3; t++)
+                acc[t].init();
+            u32x4 cur[3], nxt[3];
+            auto fetch = [&](const int k, u32x4 (&v)[3]) {
+                const uint8_t *p = pad + readlane64(off_l, k);
+#pragma unroll
+                for(int t = 0; t < 3; t++)
+                    v[t] = *reinterpret_cast<const u32x4_a4 *>(p + t * tap_stride);
+            };
+            auto reduce = [&](const u32x4 (&v)[3]) {
+#pragma unroll
+                for(int t = 0; t < 3; t++)
+                    acc[t].add(v[t]);
+            };
+            fetch(0, cur);
+            int k = 0;
+            for(; k + 1 < n_ids; k += 2) // two views per trip: the buffers swap roles without register moves
+            {
+                fetch(k + 1, nxt);
+                reduce(cur);
+                if(k + 2 < n_ids)
+                    fetch(k + 2, cur);
+                reduce(nxt);
+            }
+            if(k < n_ids)
+                reduce(cur);
+#pragma unroll
+            for(int t = 0; t < 3; t++)
+            {
+                uint16_t *dst = w.Er + ((size_t)slot * 3 + t) * w.We_p + tile * 256 + 4 * lane;
+                *reinterpret_cast<u32x2 *>(dst) = acc[t].encode();
+            }
+        }
+    }
+}
+
+// E''(tx)(qy)(slot) for the flagged columns: a lane owns one flagged column (its sample columns are the reference's
+// arithmetic for (column x, view k) plus (tx − 1)·rx), a wave takes (64 flagged columns of a candidate, 2 extended rows) units;
+// the source rows are uniform shifts.  XCD x takes the x-th eighth of the row blocks and walks it with all candidates'
+// chunks of a row block back to back (their bands overlap: one L2 serves them).  Same register-resident parameters and
+// one-view-ahead fetch as focus_lines_rows.
+constexpr int FOCUS_COL_ROWS = 2;
+__device__ __forceinline__ void focus_lines_cols(const KernelArgs &a, const FocusWork &w, const uint32_t block, const uint32_t blocks)
+{
+    constexpr int R = FOCUS_COL_ROWS;
+    const int lane = threadIdx.x & 63;
+    const uint32_t xcd = block & 7u;
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane((block >> 3) * 4 + (threadIdx.x >> 6));
+    const uint32_t n_waves = (blocks >> 3) * 4; // blocks is a multiple of 8
+    const focus_const_u32_ptr chunk_prefix = (focus_const_u32_ptr)(uintptr_t)(w.prefix + 66);
+    const focus_const_int_ptr ncols = (focus_const_int_ptr)(uintptr_t)w.ncols;
+    const uint32_t row_blocks = uint32_t(w.He_p) / uint32_t(R);
+    const uint32_t rb0 = row_blocks * xcd / 8u, rb1 = row_blocks * (xcd + 1u) / 8u;
+    const uint32_t chunks = chunk_prefix[32];
+    const int n_ids = a.n_focus_ids;
+    const int kk = lane < n_ids ? lane : 0;
+    const float offx_l = a.offsets[a.focus_ids[kk]].x;
+    const uint8_t *pad = reinterpret_cast<const uint8_t *>(w.pad);
+    const int rx = a.radius_x;
+    const size_t row_bytes = (size_t)w.Wp * 4;
+    for(uint32_t u = wave_id; u < (rb1 - rb0) * chunks; u += n_waves)
+    {
+        const uint32_t rb = rb0 + u / chunks, chunk = u % chunks;
+        int i = 0;
+        prefix_walk(chunk_prefix, chunk, i);
+        const int j = int(chunk - chunk_prefix[i]) * 64 + lane;
+        const bool listed = j < ncols[i];
+        const int x = listed ? w.cols[(size_t)i * a.width + j] : 0;
+        const uint32_t cs = line_slot(w.colbase[x], w.badx[x], i);
+        const bool active = listed && cs < uint32_t(w.C_cap);
+        if(__builtin_amdgcn_ballot_w64(active) == 0ull)
+            continue; // focus_exact (C)
+        const float f = focus_candidate(a, i);
+        // lane k: byte offset of view k's source row for the block's first extended row
+        const int sy_l = w.shifts[4 * (i * FOCUS_MAX_IDS + kk) + 1];
+        const uint64_t off_l = ((uint64_t)kk * w.Hp + uint64_t(int(rb) * R - a.radius_y + sy_l + w.Py)) * row_bytes;
+        RangeAcc1 acc[R][3]; // [row of the block][tx]
+#pragma unroll
+        for(int r = 0; r < R; r++)
+#pragma unroll
+            for(int t = 0; t < 3; t++)
+                acc[r][t].init();
+        uint32_t cur[R][3], nxt[R][3];
+        auto fetch = [&](const int k, uint32_t (&v)[R][3]) {
+            const float offx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(uint32_t, offx_l), k));
+            const uint32_t left = uint32_t(warp_float(x, f, offx) - rx + w.Px) * 4u; // tx = 0 sample column, bytes
+            const uint8_t *row = pad + readlane64(off_l, k);
+#pragma unroll
+            for(int r = 0; r < R; r++)
+#pragma unroll
+                for(int t = 0; t < 3; t++)
+                    v[r][t] = *reinterpret_cast<const uint32_t *>(row + r * row_bytes + uint32_t(t * rx) * 4u + left);
+        };
+        auto reduce = [&](const uint32_t (&v)[R][3]) {
+#pragma unroll
+            for(int r = 0; r < R; r++)
+#pragma unroll
+                for(int t = 0; t < 3; t++)
+                    acc[r][t].add(v[r][t]);
+        };
+        fetch(0, cur);
+        int k = 0;
+        for(; k + 1 < n_ids; k += 2)
+        {
+            fetch(k + 1, nxt);
+            reduce(cur);
+            if(k + 2 < n_ids)
+                fetch(k + 2, cur);
+            reduce(nxt);
+        }
+        if(k < n_ids)
+            reduce(cur);
+        if(active)
+        {
+#pragma unroll
+            for(int r = 0; r < R; r++)
+#pragma unroll
+                for(int t = 0; t < 3; t++)
+                {
+                    uint32_t range, tiny;
+                    acc[r][t].result(range, tiny);
+                    w.Ec[((size_t)t * w.He_p + rb * R + r) * w.C_cap + cs] = static_cast<uint16_t>((range << 4) + tiny);
+                }
+        }
     }
 }
 
@@ -272,14 +533,10 @@ __device__ __forceinline__ uint32_t focus_exact_key(const KernelArgs &a, const F
     const focus_const_float_ptr c_offsets = (focus_const_float_ptr)(uintptr_t)a.offsets;
     const focus_const_int_ptr c_ids = (focus_const_int_ptr)(uintptr_t)a.focus_ids;
     const size_t plane_bytes = (size_t)w.Wp * w.Hp * 4;
-    // per tap: (R, G) as a u16 pair and B
-    u16x2 lo_rg[9], hi_rg[9], lo_b[9], hi_b[9];
+    RangeAcc1 acc[9];
 #pragma unroll
     for(int t = 0; t < 9; t++)
-    {
-        lo_rg[t] = lo_b[t] = as_u16x2(0x00ff00ffu);
-        hi_rg[t] = hi_b[t] = as_u16x2(0u);
-    }
+        acc[t].init();
     const uint8_t *plane = reinterpret_cast<const uint8_t *>(w.pad);
     for(int k = 0; k < a.n_focus_ids; k++, plane += plane_bytes)
     {
@@ -295,116 +552,192 @@ __device__ __forceinline__ uint32_t focus_exact_key(const KernelArgs &a, const F
             {
                 const uint32_t tap = uint32_t(ty * ry * w.Wp + tx * rx) * 4u;
                 const uint32_t px = *reinterpret_cast<const uint32_t *>(plane + tap + corner);
-                const int t = tx * 3 + ty;
-                const u16x2 rg = as_u16x2(__builtin_amdgcn_perm(0u, px, 0x0c010c00u));
-                const u16x2 b = as_u16x2(__builtin_amdgcn_perm(0u, px, 0x0c020c02u));
-                lo_rg[t] = __builtin_elementwise_min(lo_rg[t], rg);
-                hi_rg[t] = __builtin_elementwise_max(hi_rg[t], rg);
-                lo_b[t] = __builtin_elementwise_min(lo_b[t], b);
-                hi_b[t] = __builtin_elementwise_max(hi_b[t], b);
+                acc[tx * 3 + ty].add(px);
             }
     }
     uint32_t S = 0, kmin = 0;
 #pragma unroll
     for(int t = 0; t < 9; t++)
     {
-        const uint32_t d_rg = as_u32(hi_rg[t] - lo_rg[t]), d_b = as_u32(hi_b[t] - lo_b[t]) & 0xffffu;
-        const uint32_t dmax = max(max(d_rg & 0xffffu, d_rg >> 16), d_b);
-        const uint32_t h_rg = as_u32(hi_rg[t]);
-        const uint32_t hmin = min(min(h_rg & 0xffffu, h_rg >> 16), as_u32(hi_b[t]) & 0xffffu);
-        S += dmax;
-        kmin += (dmax | hmin) == 0u ? 1u : 0u;
+        uint32_t range, tiny;
+        acc[t].result(range, tiny);
+        S += range;
+        kmin += tiny;
     }
     return S > 0 ? (S << 4) : kmin;
 }
 
-// Persistent kernel over the flagged (pixel, candidate) pairs.  The work is split by XCD (blocks b, b+8, … share one): XCD x
-// takes the flagged columns in its eighth of the rows — unit (row, candidate), candidates of a row back to back — and then
-// the flagged rows in its eighth of the 64-column chunks — unit (candidate, flagged row, chunk) — so the taps that
-// neighbouring rows, bands and candidates share meet in one L2.  gridDim.x must be a multiple of 8.
-__global__ void __launch_bounds__(256) focus_exact(const KernelArgs a, const FocusWork w)
+// Tap-by-tap keys for what the line buffers do not cover.  Persistent, three unit sequences:
+//   (A) flagged row of a candidate × that candidate's flagged columns (pairs flagged on both axes);
+//   (B) flagged rows whose line slot is ≥ R_cap × every column;   (C) flagged columns whose line slot is ≥ C_cap × every row.
+// (B) and (C) run only when there are more flagged pairs than line slots.
+__device__ __forceinline__ void focus_exact(const KernelArgs &a, const FocusWork &w, const uint32_t block, const uint32_t blocks)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t wave_id = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4 + (threadIdx.x >> 6));
-    const uint32_t n_waves = (gridDim.x >> 3) * 4;
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(block * 4 + (threadIdx.x >> 6));
+    const uint32_t n_waves = blocks * 4;
     const int W = a.width, H = a.height;
     const focus_const_u32_ptr prefix = (focus_const_u32_ptr)(uintptr_t)w.prefix;
     const focus_const_int_ptr ncols = (focus_const_int_ptr)(uintptr_t)w.ncols;
+    const uint32_t row_entries = prefix[32], col_entries = prefix[65];
 
-    // flagged columns
-    const uint32_t y0 = uint32_t(H) * xcd / 8u, y1 = uint32_t(H) * (xcd + 1u) / 8u;
-    for(uint32_t u = wave_id; u < (y1 - y0) * FOCUS_STEPS; u += n_waves)
-    {
-        const int y = int(y0 + u / FOCUS_STEPS), i = int(u % FOCUS_STEPS);
+    auto columns = [&](const int i, const int y, const bool overflow_only) { // flagged columns of candidate i in row y
         const int n = ncols[i];
         for(int idx = lane; idx - lane < n; idx += 64)
         {
-            const bool active = idx < n;
+            bool active = idx < n;
             const int x = active ? w.cols[(size_t)i * W + idx] : 0;
+            if(overflow_only)
+                active = active && line_slot(w.colbase[x], w.badx[x], i) >= uint32_t(w.C_cap);
+            if(__builtin_amdgcn_ballot_w64(active) == 0ull)
+                continue;
             const uint32_t key = focus_exact_key(a, w, x, y, i);
             if(active)
                 w.K[((size_t)i * H + y) * W + x] = static_cast<uint16_t>(key);
         }
-    }
-    // flagged rows
-    const uint32_t chunks_w = uint32_t((W + 63) / 64);
-    const uint32_t c0 = chunks_w * xcd / 8u, c1 = chunks_w * (xcd + 1u) / 8u, nc = c1 - c0;
-    const uint32_t total_rows = prefix[FOCUS_STEPS];
+    };
+    // (A)
     int i = 0;
-    for(uint32_t u = wave_id; u < total_rows * nc; u += n_waves)
+    for(uint32_t entry = wave_id; entry < row_entries; entry += n_waves)
     {
-        const uint32_t r = u / nc;
-        while(r >= prefix[i + 1])
-            i++;
-        const int y = w.rows[(size_t)i * H + (r - prefix[i])];
-        const int xx = int(c0 + u % nc) * 64 + lane;
-        const bool active = xx < W;
-        const int x = active ? xx : 0;
-        const uint32_t key = focus_exact_key(a, w, x, y, i);
-        if(active)
-            w.K[((size_t)i * H + y) * W + x] = static_cast<uint16_t>(key);
+        prefix_walk(prefix, entry, i);
+        columns(i, w.rows[(size_t)i * H + (entry - prefix[i])], false);
+    }
+    // (B)
+    if(row_entries > uint32_t(w.R_cap))
+    {
+        const uint32_t chunks_w = uint32_t((W + 63) / 64);
+        i = 0;
+        for(uint32_t u = wave_id; u < row_entries * chunks_w; u += n_waves)
+        {
+            const uint32_t entry = u / chunks_w;
+            prefix_walk(prefix, entry, i);
+            const int y = __builtin_amdgcn_readfirstlane(int(w.rows[(size_t)i * H + (entry - prefix[i])]));
+            if(__builtin_amdgcn_readfirstlane(line_slot(w.rowbase[y], w.bady[y], i)) < uint32_t(w.R_cap))
+                continue;
+            const int xx = int(u % chunks_w) * 64 + lane;
+            const bool active = xx < W;
+            const uint32_t key = focus_exact_key(a, w, active ? xx : 0, y, i);
+            if(active)
+                w.K[((size_t)i * H + y) * W + xx] = static_cast<uint16_t>(key);
+        }
+    }
+    // (C)
+    if(col_entries > uint32_t(w.C_cap))
+        for(uint32_t u = wave_id; u < uint32_t(FOCUS_STEPS) * uint32_t(H); u += n_waves)
+            columns(int(u / uint32_t(H)), int(u % uint32_t(H)), true);
+}
+
+// The three passes over flagged pairs are independent, small and latency-bound: one launch, the workgroups split between
+// them (gridDim.x = 3·per_pass, per_pass a multiple of 8), so that they run side by side — next to focus_range on the
+// main stream — instead of one after the other.
+__global__ void __launch_bounds__(256) focus_flagged(const KernelArgs a, const FocusWork w, const uint32_t per_pass)
+{
+    const uint32_t pass = blockIdx.x / per_pass, block = blockIdx.x % per_pass; // wave-uniform
+    if(pass == 0)
+        focus_lines_rows(a, w, block, per_pass);
+    else if(pass == 1)
+        focus_lines_cols(a, w, block, per_pass);
+    else
+        focus_exact(a, w, block, per_pass);
+}
+
+// K for the pairs flagged on one axis: the nine samples of the row lines Er / column lines Ec, summed and encoded, so that
+// focus_pick has a single override source.  Persistent, two unit sequences:
+//   (R) flagged row of a candidate (line slot < R_cap) × 64-column chunk, skipping the columns flagged for that candidate;
+//   (C) 64 flagged columns of a candidate (line slot < C_cap) × block of 8 rows, skipping the rows flagged for it.
+__global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const FocusWork w)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * 4;
+    const int W = a.width, H = a.height, rx = a.radius_x, ry = a.radius_y;
+    const focus_const_u32_ptr prefix = (focus_const_u32_ptr)(uintptr_t)w.prefix;
+    const focus_const_u32_ptr chunk_prefix = prefix + 66;
+    const focus_const_int_ptr ncols = (focus_const_int_ptr)(uintptr_t)w.ncols;
+    auto encode = [](const uint32_t sum) { return sum >= 16u ? (sum & ~15u) : sum; };
+    // (R)
+    const uint32_t chunks_w = uint32_t((W + 63) / 64);
+    int i = 0;
+    for(uint32_t u = wave_id; u < prefix[32] * chunks_w; u += n_waves)
+    {
+        const uint32_t entry = u / chunks_w;
+        prefix_walk(prefix, entry, i);
+        const int y = __builtin_amdgcn_readfirstlane(int(w.rows[(size_t)i * H + (entry - prefix[i])]));
+        const uint32_t slot = __builtin_amdgcn_readfirstlane(line_slot(w.rowbase[y], w.bady[y], i));
+        if(slot >= uint32_t(w.R_cap))
+            continue; // focus_exact (B)
+        const int x = int(u % chunks_w) * 64 + lane;
+        if(x >= W || ((w.badx[x] >> i) & 1u))
+            continue; // flagged on both axes: focus_exact (A)
+        const uint16_t *line = w.Er + (size_t)slot * 3 * w.We_p + x;
+        uint32_t sum = 0;
+#pragma unroll
+        for(int ty = 0; ty < 3; ty++)
+#pragma unroll
+            for(int tx = 0; tx < 3; tx++)
+                sum += line[(size_t)ty * w.We_p + tx * rx];
+        w.K[((size_t)i * H + y) * W + x] = static_cast<uint16_t>(encode(sum));
+    }
+    // (C)
+    constexpr int ROWS = 8;
+    const uint32_t row_blocks = uint32_t(H + ROWS - 1) / ROWS;
+    for(uint32_t u = wave_id; u < chunk_prefix[32] * row_blocks; u += n_waves)
+    {
+        const uint32_t chunk = u / row_blocks, rb = u % row_blocks;
+        int ci = 0;
+        prefix_walk(chunk_prefix, chunk, ci);
+        const int j = int(chunk - chunk_prefix[ci]) * 64 + lane;
+        if(j >= ncols[ci])
+            continue;
+        const int x = w.cols[(size_t)ci * W + j];
+        const uint32_t cs = line_slot(w.colbase[x], w.badx[x], ci);
+        if(cs >= uint32_t(w.C_cap))
+            continue; // focus_exact (C)
+        for(int y = int(rb) * ROWS; y < min(int(rb) * ROWS + ROWS, H); y++)
+        {
+            if((w.bady[y] >> ci) & 1u)
+                continue; // focus_exact (A)
+            uint32_t sum = 0;
+#pragma unroll
+            for(int tx = 0; tx < 3; tx++)
+#pragma unroll
+                for(int ty = 0; ty < 3; ty++)
+                    sum += w.Ec[((size_t)tx * w.He_p + y + ty * ry) * w.C_cap + cs];
+            w.K[((size_t)ci * H + y) * W + x] = static_cast<uint16_t>(encode(sum));
+        }
     }
 }
 
-// dispersion per candidate = nine samples of E (or the exact key where flagged); first strict minimum → map 0.
+// dispersion per candidate = nine samples of E, or K where the pair is flagged on either axis; first strict minimum → map 0.
 // Blocks of 4 rows × 64·PPL pixels, a lane owns PPL ∈ {1, 2} adjacent pixels; PPL = 2 reads both pixels' samples with one
 // dword load and needs an even radius_x (the E columns x + rx ± rx of an even x are then dword aligned) — the reference always
-// produces one (src/interpolator.cu:143-146).  Vertical stripes per XCD (stripe_map) keep the ±r rows of all 32 candidates in
-// one L2 (row bands per XCD for images narrower than 8 blocks).  Every sample is scalar plane base + per-lane tap offset.
+// produces one (src/interpolator.cu:143-146).  Every sample is scalar plane base + per-lane tap offset.  Row-major block
+// order, consecutive blocks on different XCDs: the flagged rows sit at the top of the image and the flagged columns at its
+// left, so neither row bands nor column stripes per XCD would spread the waves that also read K evenly.
 template <int PPL>
-__global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const FocusWork w, const uint32_t nblocks, const int striped)
+__global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const FocusWork w)
 {
     const int W = a.width, H = a.height;
-    const uint32_t blocks_x = uint32_t(W + 64 * PPL - 1) / uint32_t(64 * PPL), blocks_y = uint32_t(H + 3) / 4u;
-    uint32_t bx, by, unused;
-    if(striped)
-    {
-        if(!stripe_map(blockIdx.x, blocks_x, blocks_y, 1u, bx, by, unused))
-            return;
-    }
-    else
-    {
-        const uint32_t block = xcd_contiguous(blockIdx.x, nblocks);
-        bx = block % blocks_x;
-        by = block / blocks_x;
-    }
+    const uint32_t blocks_x = uint32_t(W + 64 * PPL - 1) / uint32_t(64 * PPL);
+    const uint32_t bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
     const int x = (int(bx) * 64 + int(threadIdx.x & 63)) * PPL;
-    const int y = int(by) * 4 + int(threadIdx.x >> 6);
+    const int y = __builtin_amdgcn_readfirstlane(int(by) * 4 + int(threadIdx.x >> 6));
     if(y >= H) // wave-uniform
         return;
     const int rx = a.radius_x, ry = a.radius_y;
     // lanes past the right edge compute pixel 0 and store nothing; the second pixel of a lane at x = W − 1 (odd W) reads
     // one element past a row of badx / E / K, inside the workspace, and is not stored either
     const int xs = x < W ? x : 0;
+    const uint32_t flagged_y = __builtin_amdgcn_readfirstlane(w.bady[y]);
     uint32_t flagged[PPL];
-#pragma unroll
-    for(int j = 0; j < PPL; j++)
-        flagged[j] = w.badx[xs + j] | w.bady[y];
     bool any = false;
 #pragma unroll
     for(int j = 0; j < PPL; j++)
+    {
+        flagged[j] = w.badx[xs + j] | flagged_y;
         any = any || flagged[j] != 0u;
+    }
     const bool wave_flagged = __builtin_amdgcn_ballot_w64(any) != 0ull;
 
     uint32_t tap[9]; // byte offsets of the nine samples inside a candidate's plane of E
@@ -449,7 +782,7 @@ __global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const Focu
             uint32_t key = sum[j] >= 16u ? (sum[j] & ~15u) : sum[j];
             if(with_exact)
             {
-                const uint32_t k_exact = exact[j]; // unconditional: flagged lanes are rare, a divergent load costs more
+                const uint32_t k_exact = exact[j]; // unconditional: a divergent load costs more than the unused values
                 key = ((flagged[j] >> i) & 1u) ? k_exact : key;
             }
             if(key < best_key[j]) // MinDispersion::add (src/kernels.cu:225-231): strict <
@@ -463,7 +796,7 @@ __global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const Focu
     };
     if(wave_flagged)
     {
-#pragma unroll 2
+#pragma unroll 4
         for(int i = 0; i < FOCUS_STEPS; i++)
             candidate(i, true);
     }

@@ -49,6 +49,9 @@ struct lfi_ctx
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // side stream of the factored focus-map estimate (its small passes overlap the large ones), created on first use
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_pad = nullptr, ev_join = nullptr;
     int cols = 0, rows = 0, n = 0, width = 0, height = 0;
     // row window (lfi_set_row_window): input rows held / output rows rendered; the whole image by default
     int in_y0 = 0, in_rows = 0, out_y0 = 0, out_rows = 0;
@@ -416,7 +419,14 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     const size_t o_badx = carve(sizeof(uint32_t) * W), o_bady = carve(sizeof(uint32_t) * H);
     const size_t o_cols = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * W), o_rows = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * H);
     const size_t o_ncols = carve(sizeof(int32_t) * lfi::FOCUS_STEPS), o_nrows = carve(sizeof(int32_t) * lfi::FOCUS_STEPS);
-    const size_t o_prefix = carve(sizeof(uint32_t) * (2 * lfi::FOCUS_STEPS + 1));
+    const size_t o_prefix = carve(sizeof(uint32_t) * 3 * 33);
+    const size_t o_rowbase = carve(sizeof(uint32_t) * H), o_colbase = carve(sizeof(uint32_t) * (W + 1));
+    // line buffers for 4× the typical number of flagged rows / columns (three bands of r per candidate ≈ 0.03·H each);
+    // anything beyond takes the tap-by-tap path
+    w.R_cap = 4 * H;
+    w.C_cap = 4 * W;
+    const size_t o_Er = carve(sizeof(uint16_t) * (size_t)w.R_cap * 3 * w.We_p);
+    const size_t o_Ec = carve(sizeof(uint16_t) * (size_t)w.C_cap * 3 * w.He_p);
     const size_t o_E = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * (size_t)w.He_p * w.We_p);
     const size_t o_K = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * (size_t)H * W);
     const size_t o_deltas = carve(sizeof(int64_t) * lfi::FOCUS_STEPS * lfi::FOCUS_MAX_IDS);
@@ -439,38 +449,61 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     w.ncols = reinterpret_cast<int32_t *>(base + o_ncols);
     w.nrows = reinterpret_cast<int32_t *>(base + o_nrows);
     w.prefix = reinterpret_cast<uint32_t *>(base + o_prefix);
+    w.rowbase = reinterpret_cast<uint32_t *>(base + o_rowbase);
+    w.colbase = reinterpret_cast<uint32_t *>(base + o_colbase);
+    w.Er = reinterpret_cast<uint16_t *>(base + o_Er);
+    w.Ec = reinterpret_cast<uint16_t *>(base + o_Ec);
     w.E = reinterpret_cast<uint16_t *>(base + o_E);
     w.K = reinterpret_cast<uint16_t *>(base + o_K);
     w.deltas = reinterpret_cast<int64_t *>(base + o_deltas);
     w.pad = reinterpret_cast<uint32_t *>(base + o_pad);
+    // Two streams: the plan and the flagged-pair passes are small, latency-bound kernels; they run beside the padded copy
+    // and the range pass (bandwidth / VALU bound) instead of in front of them.
+    //   main:  plan_shifts ─┬─ pad ─┬─ range ───────────────────────────────┬─ pick (→ filter, by the caller)
+    //   aux:                └─ flags → lists → prefix ─┴─ {lines_rows, lines_cols, exact} → line_keys ─────┘
+    if(!ctx->aux_stream)
+    {
+        int prio_low = 0, prio_high = 0; // numerically lower = higher priority: the small passes should not queue behind the big ones
+        LFI_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        LFI_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio_high));
+        LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pad, hipEventDisableTiming));
+        LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
     hipStream_t st = ctx->stream;
-    LFI_HIP(ctx, hipMemsetAsync(w.badx, 0, o_cols - o_badx, st)); // badx and bady are adjacent
+    hipStream_t aux = ctx->aux_stream;
     hipLaunchKernelGGL(lfi::focus_plan_shifts, dim3(1), dim3(1024), 0, st, a, w);
-    hipLaunchKernelGGL(lfi::focus_plan_flags, dim3((std::max(W, H) + 255) / 256, lfi::FOCUS_STEPS, 2), dim3(256), 0, st, a, w);
-    hipLaunchKernelGGL(lfi::focus_plan_lists, dim3(lfi::FOCUS_STEPS, 2), dim3(64), 0, st, a, w);
-    hipLaunchKernelGGL(lfi::focus_plan_prefix, dim3(1), dim3(1), 0, st, a, w);
+    LFI_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+    LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_fork, 0));
+    LFI_HIP(ctx, hipMemsetAsync(w.badx, 0, o_cols - o_badx, aux)); // badx and bady are adjacent
+    hipLaunchKernelGGL(lfi::focus_plan_flags, dim3((std::max(W, H) + 255) / 256, lfi::FOCUS_STEPS, 2), dim3(256), 0, aux, a, w);
+    hipLaunchKernelGGL(lfi::focus_plan_lists, dim3(lfi::FOCUS_STEPS, 2), dim3(64), 0, aux, a, w);
+    hipLaunchKernelGGL(lfi::focus_plan_prefix, dim3(1), dim3(1), 0, aux, a, w);
     hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, ctx->n_focus_ids), dim3(64), 0, st, a, w);
+    LFI_HIP(ctx, hipEventRecord(ctx->ev_pad, st));
+    LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_pad, 0));
     const uint32_t tiles_x = uint32_t(w.We_p / 256), tiles_y = uint32_t(w.He_p / 4);
-    const char *stripe_env = getenv("LFI_FOCUS_STRIPES");
-    const bool allow_stripes = !stripe_env || atoi(stripe_env) != 0;
     {
         constexpr int CPW = 4, GROUPS = lfi::FOCUS_STEPS / CPW;
-        const int striped = allow_stripes && tiles_x >= 8;
+        const int striped = tiles_x >= 8;
         const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(tiles_x, tiles_y, GROUPS) : tiles_x * tiles_y * GROUPS;
         hipLaunchKernelGGL(lfi::focus_range<CPW>, dim3(nblocks), dim3(256), 0, st, a, w, nblocks, striped);
     }
-    hipLaunchKernelGGL(lfi::focus_exact, dim3(ctx->cu_count * 4), dim3(256), 0, st, a, w);
     {
-        // two pixels per lane need dword-aligned sample pairs: even radius_x (the reference's is), and an even K pitch
-        const char *ppl_env = getenv("LFI_FOCUS_PICK_PPL");
-        const int ppl = (rx % 2 == 0 && W >= 2 && !(ppl_env && atoi(ppl_env) == 1)) ? 2 : 1;
-        const uint32_t bx = uint32_t((W + 64 * ppl - 1) / (64 * ppl)), by = uint32_t((H + 3) / 4);
-        const int striped = allow_stripes && bx >= 8;
-        const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(bx, by, 1u) : bx * by;
+        const uint32_t per_pass = uint32_t(ctx->cu_count) * 4u / 8u * 8u;
+        hipLaunchKernelGGL(lfi::focus_flagged, dim3(3 * per_pass), dim3(256), 0, aux, a, w, per_pass);
+    }
+    hipLaunchKernelGGL(lfi::focus_line_keys, dim3(ctx->cu_count * 8), dim3(256), 0, aux, a, w);
+    LFI_HIP(ctx, hipEventRecord(ctx->ev_join, aux));
+    LFI_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+    {
+        // two pixels per lane need dword-aligned sample pairs: even radius_x (the reference's is)
+        const int ppl = (rx % 2 == 0 && W >= 2) ? 2 : 1;
+        const uint32_t nblocks = uint32_t((W + 64 * ppl - 1) / (64 * ppl)) * uint32_t((H + 3) / 4);
         if(ppl == 2)
-            hipLaunchKernelGGL(lfi::focus_pick<2>, dim3(nblocks), dim3(256), 0, st, a, w, nblocks, striped);
+            hipLaunchKernelGGL(lfi::focus_pick<2>, dim3(nblocks), dim3(256), 0, st, a, w);
         else
-            hipLaunchKernelGGL(lfi::focus_pick<1>, dim3(nblocks), dim3(256), 0, st, a, w, nblocks, striped);
+            hipLaunchKernelGGL(lfi::focus_pick<1>, dim3(nblocks), dim3(256), 0, st, a, w);
     }
     LFI_HIP(ctx, hipGetLastError());
     *done = true;
@@ -586,6 +619,14 @@ int lfi_destroy(lfi_ctx *ctx)
         (void)hipEventDestroy(ctx->ev0);
     if(ctx->ev1)
         (void)hipEventDestroy(ctx->ev1);
+    if(ctx->ev_fork)
+        (void)hipEventDestroy(ctx->ev_fork);
+    if(ctx->ev_pad)
+        (void)hipEventDestroy(ctx->ev_pad);
+    if(ctx->ev_join)
+        (void)hipEventDestroy(ctx->ev_join);
+    if(ctx->aux_stream)
+        (void)hipStreamDestroy(ctx->aux_stream);
     if(ctx->own_stream)
         (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
