@@ -131,6 +131,7 @@ class Context:
         self.device = device
         self.cols = self.rows = self.width = self.height = self.views = 0
         self._keep = None
+        self._pinned = []
 
     # -- helpers --------------------------------------------------------------------------------------------
     def _check(self, rc: int) -> None:
@@ -139,6 +140,9 @@ class Context:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            for p in self._pinned: # arrays from pinned_empty must not be used after this
+                self._lib.lfi_free_pinned(C.c_void_p(p))
+            self._pinned = []
             self._lib.lfi_destroy(self._h)
             self._h = None
 
@@ -260,15 +264,32 @@ class Context:
         return self._lib.lfi_list_variants(m).decode().split(",")
 
     # -- results -------------------------------------------------------------------------------------------------
-    def download_view(self, v: int) -> np.ndarray:
-        """Whole-image array; with a row window only rows [out_y0, out_y1) are filled (the rest stays zero)."""
-        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+    def download_view(self, v: int, out: np.ndarray | None = None) -> np.ndarray:
+        """Whole-image array; with a row window only rows [out_y0, out_y1) are filled (the rest stays zero).
+        `out` may be a page-locked array from `pinned_empty` (a true DMA instead of a staged copy)."""
+        if out is None:
+            out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        assert out.shape == (self.height, self.width, 4) and out.dtype == np.uint8 and out.flags.c_contiguous
         self._check(self._lib.lfi_download_view(self._h, v, _ptr(out), self.width * 4))
         return out
 
-    def download_views(self, v0: int = 0, v1: int | None = None) -> np.ndarray:
+    def download_views(self, v0: int = 0, v1: int | None = None, out: np.ndarray | None = None) -> np.ndarray:
         v1 = self.views if v1 is None else v1
-        return np.stack([self.download_view(v) for v in range(v0, v1)])
+        if out is None:
+            return np.stack([self.download_view(v) for v in range(v0, v1)])
+        assert out.shape == (v1 - v0, self.height, self.width, 4)
+        for v in range(v0, v1):
+            self.download_view(v, out[v - v0])
+        return out
+
+    def pinned_empty(self, shape, dtype=np.uint8) -> np.ndarray:
+        """A numpy array over page-locked host memory (lfi_alloc_pinned); freed when the context is closed."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._check(self._lib.lfi_alloc_pinned(nbytes, C.byref(p)))
+        self._pinned.append(p.value)
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def download_quilt(self, tiles_x: int, tiles_y: int, v0: int = 0) -> np.ndarray:
         out = np.empty((tiles_y * self.height, tiles_x * self.width, 4), dtype=np.uint8)

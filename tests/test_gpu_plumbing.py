@@ -118,3 +118,25 @@ def test_bench_json_contract(gpu):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "views/s" and "sample" in c
     assert d["value"] > 100 * c["value"]
+
+
+def test_pinned_host_buffers(gpu, oracle_c):
+    """Uploads from / downloads into page-locked arrays (lfi_alloc_pinned) give the same bytes as pageable ones."""
+    cols, rows, W, H = 4, 4, 96, 40
+    hp = gpu.build_params(cols, rows, W, H, "0.1,0.2,0.8,0.9", 0.1, 0.0, 2.0, 1.5, 6)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, 5)
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    pin_in = ctx.pinned_empty(lf.shape)
+    pin_in[...] = lf
+    ctx.upload_grid(pin_in)
+    ctx.set_params(hp)
+    ctx.render("STD")
+    ctx.sync()
+    want = ctx.download_views()
+    pin_out = ctx.pinned_empty(want.shape)
+    got = ctx.download_views(out=pin_out)
+    assert got is pin_out and (got == want).all()
+    assert (want == oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)).all()
+    ctx.close()
+
