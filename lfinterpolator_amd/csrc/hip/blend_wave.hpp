@@ -1,0 +1,301 @@
+// blend_wave.hpp — TEN_WM / STD with a private LDS-DMA pipeline per WAVE (no workgroup barrier in the tile loop).
+//
+// blend_persist (blend_ten_persist.hpp) shares one 128-pixel tile between the four waves of a workgroup: every wave fetches a
+// quarter of the images for all 128 pixels, so a barrier per unit couples the waves — and, through the matrix pipe that each
+// SIMD's two resident waves share, the two workgroups of a CU: they drift into the same phase and their epilogues and DMA
+// issue stop overlapping the other's MFMAs (profiles/r01_notes.md, STD ablations).  Here each wave owns 32 pixels of the tile
+// and fetches ALL images for them into its own double buffer (64 images × 128 B = 8 KB per buffer), so nothing in the loop
+// waits for another wave.  The price: the weight fragments must not change from unit to unit — they are loaded once per
+// workgroup — so this kernel serves launches with one K-chunk (≤ 64 images) and one view pass (≤ 32·MT views): BASELINE
+// configs 1, 2 and 4, each bench step.  Everything else takes blend_persist.
+//
+//      per wave, per tile:   s_waitcnt vmcnt(#stores of the previous epilogue)   → the tile's 8 DMA pieces have landed
+//                            issue the 8 LDS-DMA pieces of the next tile into the other buffer
+//                            compute the tile from LDS (same operand maps as blend_persist)
+//                            epilogue + 32 stores
+//
+// LDS: 8 KB weight fragments + 4 waves × 2 × 8 KB = 72 KB per workgroup, two workgroups per CU.
+// Contraction, operand maps, subnormal-pixel trick and packed epilogue: blend_ten.hpp / blend_ten_lds.hpp / blend_ten_persist.hpp.
+// Replaces Kernels::Tensors::process<false> / Kernels::Standard::process<false> (reference src/kernels.cu:289-343, 398-461).
+#pragma once
+
+#include "blend_ten_persist.hpp"
+
+namespace lfi {
+
+template <bool STD, int MT, bool NT_STORE>
+__global__ void __launch_bounds__(256, 2) blend_wave(const KernelArgs a, const int tiles_x, const int n_tiles)
+{
+    constexpr int KC = 64, KS = KC / 16, VPP = MT * 32, TPX = 32;
+    constexpr int W_DW = (KC / 8) * VPP * 4; // weight fragments [k-octet][view] × 16 B
+    constexpr int PX_DW = KC * TPX;          // one pixel buffer of one wave
+    __shared__ __attribute__((aligned(16))) uint32_t lds[W_DW + 4 * 2 * PX_DW];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int W = a.width, H = a.height;
+    const uint32_t *grid32 = reinterpret_cast<const uint32_t *>(a.grid);
+    const size_t plane_px = (size_t)W * (size_t)a.in_rows;   // one input plane as held by this context
+    const size_t oplane_px = (size_t)W * (size_t)a.out_rows; // one output plane
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr_t)lds)));
+    const uint32_t px_base = lds_base + W_DW * 4 + uint32_t(wave) * (2 * PX_DW * 4);
+    const int kc = a.k_pad; // ≤ KC (host)
+
+    // ---- once per workgroup: the weight fragments (as blend_persist's issue(), all four waves) ---------------------------
+    for(int o = wave; 8 * o < kc; o += 4)
+        if(lane < VPP)
+            dma16((STD ? a.w16 : a.w16s) + (size_t)(a.v0 + lane) * a.k_pad + 8 * o, lds_base + uint32_t(o) * (VPP * 16));
+
+    // ---- per lane, once: the integer offsets of the image this lane fetches in each of the 8 DMA pieces ---------------------
+    // piece i moves images 8i … 8i+7, eight lanes (16 B = 4 pixels each) per image: lane l ↔ image 8i + (l >> 3), pixels 4(l & 7)…
+    int ox[8], oy[8], gi[8];
+#pragma unroll
+    for(int i = 0; i < 8; i++)
+    {
+        gi[i] = min(8 * i + (lane >> 3), a.n_images - 1); // padded images (zero weights) re-read the last one
+        const lfi_int2 o = a.focused[gi[i]];
+        ox[i] = o.x;
+        oy[i] = o.y;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); // the only one: weights in LDS
+    asm volatile("" ::: "memory");
+
+    auto issue = [&](const int t, const int buf) {
+        const int ty = t / tiles_x;
+        const int y = a.out_y0 + ty; // global row
+        const int xw = (t - ty * tiles_x) * 128 + wave * TPX;
+        const uint32_t dst = px_base + uint32_t(buf) * (PX_DW * 4);
+#pragma unroll
+        for(int i = 0; i < 8; i++)
+        {
+            if(8 * i >= kc)
+                break;
+            const int sy = clampi(y + oy[i], 0, H - 1) - a.in_y0; // clamp in the full image, then index the held rows
+            const int sx = xw + ox[i] + 4 * (lane & 7);
+            const bool inside = sx >= 0 && sx + 4 <= W;
+            if(__builtin_amdgcn_ballot_w64(inside) == ~0ull)
+                dma16(grid32 + (size_t)gi[i] * plane_px + (size_t)sy * W + sx, dst + uint32_t(i) * 1024u);
+            else
+            {
+                // a run crosses the left / right border: per-pixel clamp-to-edge addresses (reference src/kernels.cu:125),
+                // two images × 32 pixels per instruction; the image's offsets come from the lane that holds them
+#pragma unroll
+                for(int s = 0; s < 4; s++)
+                {
+                    const int src_lane = 8 * (2 * s + h);
+                    const int g = __builtin_amdgcn_ds_bpermute(4 * src_lane, gi[i]);
+                    const int oxi = __builtin_amdgcn_ds_bpermute(4 * src_lane, ox[i]);
+                    const int oyi = __builtin_amdgcn_ds_bpermute(4 * src_lane, oy[i]);
+                    const int syy = clampi(y + oyi, 0, H - 1) - a.in_y0;
+                    const int sxx = clampi(xw + oxi + r, 0, W - 1);
+                    dma4(grid32 + (size_t)g * plane_px + (size_t)syy * W + sxx, dst + uint32_t(i) * 1024u + uint32_t(s) * 256u);
+                }
+            }
+        }
+    };
+
+    // ---- this workgroup's tiles j, j+G, j+2G …; a wave whose 32 pixels start beyond the row's end skips the tile ------------
+    const int G = gridDim.x;
+    auto has_pixels = [&](const int t) { return (t % tiles_x) * 128 + wave * TPX < W; };
+    auto next_tile = [&](int t) {
+        do
+            t += G;
+        while(t < n_tiles && !has_pixels(t));
+        return t;
+    };
+    int t = int(xcd_contiguous(blockIdx.x, gridDim.x));
+    if(t < n_tiles && !has_pixels(t))
+        t = next_tile(t);
+    if(t >= n_tiles)
+        return;
+    int buf = 0;
+    int prev_stores = 0; // store instructions of the previous epilogue (the youngest VMEM operations of this wave)
+    issue(t, 0);
+
+    // the first MFMA of a tile takes a zero C operand (an inline constant): the accumulators are never cleared
+    f32x16 acc[MT][3];
+    f32x16 zero16;
+#pragma unroll
+    for(int e = 0; e < 16; e++)
+        zero16[e] = 0.0f;
+
+    const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(lds);
+    while(true)
+    {
+        const int nt = next_tile(t);
+        // this wave's pieces of the current tile have landed; the previous epilogue's stores may still be in flight (vmcnt
+        // retires in order and the stores are the youngest operations)
+        if(prev_stores >= 32)
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if(prev_stores >= 24)
+            asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if(prev_stores >= 16)
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if(prev_stores >= 8)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if(nt < n_tiles)
+            issue(nt, buf ^ 1); // this wave finished reading that buffer one tile ago (program order)
+
+        // ---- compute the tile ------------------------------------------------------------------------------------------------
+        const uint32_t *px_buf = lds + W_DW + wave * (2 * PX_DW) + buf * PX_DW;
+        if constexpr(!STD)
+        {
+            const uint32_t *col = px_buf + r + 8 * h * TPX; // this lane's pixel column, first image of its k-half
+#pragma unroll
+            for(int ks = 0; ks < KS; ks++)
+            {
+                if(16 * ks < kc)
+                {
+                    half8 wfrag[MT];
+#pragma unroll
+                    for(int m = 0; m < MT; m++)
+                        wfrag[m] = __builtin_bit_cast(half8, w_buf[(2 * ks + h) * VPP + m * 32 + r]);
+                    uint32_t px[8];
+#pragma unroll
+                    for(int j = 0; j < 8; j++)
+                        px[j] = col[(16 * ks + j) * TPX];
+                    u32x4 bc[3];
+#pragma unroll
+                    for(int q = 0; q < 4; q++)
+                    {
+                        bc[0][q] = pack_subnormal_pair<0>(px[2 * q], px[2 * q + 1]);
+                        bc[1][q] = pack_subnormal_pair<1>(px[2 * q], px[2 * q + 1]);
+                        bc[2][q] = pack_subnormal_pair<2>(px[2 * q], px[2 * q + 1]);
+                    }
+#pragma unroll
+                    for(int c = 0; c < 3; c++)
+                    {
+                        const half8 bfrag = __builtin_bit_cast(half8, bc[c]);
+#pragma unroll
+                        for(int m = 0; m < MT; m++)
+                            acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[m], bfrag, ks == 0 ? zero16 : acc[m][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        else
+        {
+            // exact fp32 (see blend_persist): MFMA q of a k-step multiplies image pair (16ks+2q, 16ks+2q+1), ascending
+            const uint32_t *col = px_buf + r + h * TPX;
+            uint32_t px[2][8];
+            u32x4 wlo[2][MT], whi[2][MT];
+            auto load_step = [&](int ks, int slot) {
+#pragma unroll
+                for(int q = 0; q < 8; q++)
+                    px[slot][q] = col[(16 * ks + 2 * q) * TPX];
+#pragma unroll
+                for(int m = 0; m < MT; m++)
+                {
+                    wlo[slot][m] = w_buf[(2 * ks) * VPP + m * 32 + r];
+                    whi[slot][m] = w_buf[(2 * ks + 1) * VPP + m * 32 + r];
+                }
+            };
+            const uint32_t sh = 16u * uint32_t(h);
+            load_step(0, 0);
+#pragma unroll
+            for(int ks = 0; ks < KS; ks++)
+            {
+                if(16 * ks < kc)
+                {
+                    const int cur = ks & 1;
+                    if(ks + 1 < KS && 16 * (ks + 1) < kc)
+                        load_step(ks + 1, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for(int q = 0; q < 8; q++)
+                    {
+                        float wq[MT];
+#pragma unroll
+                        for(int m = 0; m < MT; m++)
+                        {
+                            const uint32_t d = q < 4 ? wlo[cur][m][q] : whi[cur][m][q - 4];
+                            wq[m] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(d >> sh))); // exact
+                        }
+                        const uint32_t p = px[cur][q];
+                        const float pc[3] = {static_cast<float>(p & 0xffu), static_cast<float>((p >> 8) & 0xffu),
+                                             static_cast<float>((p >> 16) & 0xffu)};
+#pragma unroll
+                        for(int c = 0; c < 3; c++)
+#pragma unroll
+                            for(int m = 0; m < MT; m++)
+                                acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[m], pc[c], (ks == 0 && q == 0) ? zero16 : acc[m][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue ------------------------------------------------------------------------------------------------------------
+        {
+            // STD is bound by the matrix pipe the SIMD's two waves share: this wave's epilogue (VALU + stores) should run
+            // under the other wave's MFMAs and be over quickly, not take the issue slots that wave leaves (measured −3 %)
+            if constexpr(STD)
+                __builtin_amdgcn_s_setprio(1);
+            const int y = t / tiles_x; // row inside the output window
+            const int xw = (t - y * tiles_x) * 128 + wave * TPX;
+            int n_st = 0; // exact count of store instructions issued below (every branch around a store is wave-uniform)
+#pragma unroll
+            for(int m = 0; m < MT; m++)
+            {
+                const int view_m = a.v0 + m * 32;
+                const int nvalid = min(a.v1 - view_m, 32); // views of this M-tile inside the launch's range
+                if(nvalid > 0)
+                {
+                    uint32_t rgba[16];
+                    if constexpr(STD)
+                        quantize_tile_rn(acc[m][0], acc[m][1], acc[m][2], rgba);
+                    else
+                        quantize_tile_packed(acc[m][0], acc[m][1], acc[m][2], rgba);
+                    uint32_t *ubase = reinterpret_cast<uint32_t *>(a.views) + (size_t)view_m * oplane_px + (size_t)y * W + xw;
+                    const uint32_t lane_off = uint32_t(r) + uint32_t(4 * h) * uint32_t(oplane_px);
+                    if(nvalid == 32 && xw + 32 <= W)
+                    {
+                        n_st += 16; // full M-tile, full run: 16 unpredicated stores
+#pragma unroll
+                        for(int e = 0; e < 16; e++)
+                        {
+                            uint32_t *out = ubase + (size_t)((e & 3) + 8 * (e >> 2)) * oplane_px + lane_off;
+                            if constexpr(NT_STORE)
+                                __builtin_nontemporal_store(rgba[e], out);
+                            else
+                                *out = rgba[e];
+                        }
+                    }
+                    else
+                    {
+                        const bool lane_x_ok = xw + r < W;
+#pragma unroll
+                        for(int e = 0; e < 16; e++)
+                        {
+                            const int vrow = (e & 3) + 8 * (e >> 2); // + 4h in lane_off
+                            if(vrow < nvalid) // wave-uniform; lane (r = 0, h = 0) is then always active, so the store is issued
+                            {
+                                n_st++;
+                                uint32_t *out = ubase + (size_t)vrow * oplane_px + lane_off;
+                                if(lane_x_ok && vrow + 4 * h < nvalid)
+                                {
+                                    if constexpr(NT_STORE)
+                                        __builtin_nontemporal_store(rgba[e], out);
+                                    else
+                                        *out = rgba[e];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            prev_stores = n_st;
+            if constexpr(STD)
+                __builtin_amdgcn_s_setprio(0);
+        }
+        if(nt >= n_tiles)
+            break;
+        t = nt;
+        buf ^= 1;
+    }
+}
+
+} // namespace lfi

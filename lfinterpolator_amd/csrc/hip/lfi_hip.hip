@@ -19,6 +19,7 @@
 #include "blend_ten.hpp"
 #include "blend_ten_lds.hpp"
 #include "blend_ten_persist.hpp"
+#include "blend_wave.hpp"
 #include "focus_factored.hpp"
 #include "lfi_device.hpp"
 
@@ -231,6 +232,21 @@ void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
         hipLaunchKernelGGL((lfi::blend_persist<STD, MT, false, NT_STORE, KC, WGS>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
 }
 
+// wave-private pipelines (blend_wave.hpp) where they apply — fixed focus, one K-chunk, one view pass — else blend_persist
+template <bool STD, int MT, bool NT_STORE>
+void launch_wave(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    if(all_focus || a.k_pad > 64 || a.v1 - a.v0 > 32 * MT)
+    {
+        launch_persist<STD, MT, NT_STORE>(c, a, all_focus);
+        return;
+    }
+    const int tiles_x = (a.width + 127) / 128;
+    const int n_tiles = tiles_x * a.out_rows;
+    const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    hipLaunchKernelGGL((lfi::blend_wave<STD, MT, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles);
+}
+
 template <int PXL, int MT>
 void launch_std_mfma(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
@@ -258,6 +274,7 @@ void launch_std_valu(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 const Variant kTenVariants[] = {
     {"persist_m2_nt", launch_persist<false, 2, true>, true, false, true},
     {"persist_m2", launch_persist<false, 2, false>, true, false, true},
+    {"wave_m2_nt", launch_wave<false, 2, true>, true, false, true},
     {"direct_p1m2", launch_ten_direct<1, 2>, false, true},
     {"persist_m1", launch_persist<false, 1, true>, true, false, true},
     {"lds_n1m2_w3", launch_ten_lds<1, 2, 4, 1, 64, 3>, true},
@@ -270,6 +287,7 @@ const Variant kTenVariants[] = {
     {"direct_p1m1", launch_ten_direct<1, 1>, false, true},
 };
 const Variant kStdVariants[] = {
+    {"wave_m2_nt", launch_wave<true, 2, true>, false, false, true}, // blend_persist where blend_wave does not apply
     {"persist_m2_nt", launch_persist<true, 2, true>, false, false, true},
     {"persist_m1_nt", launch_persist<true, 1, true>, false, false, true},
     {"mfma_p1m2", launch_std_mfma<1, 2>, false, true}, {"mfma_p2m2", launch_std_mfma<2, 2>, false, true}, {"mfma_p2m1", launch_std_mfma<2, 1>, false, true},
