@@ -15,7 +15,7 @@
 //                            epilogue + 32 stores
 //
 // LDS: 8 KB weight fragments + 4 waves × 2 × 8 KB = 72 KB per workgroup, two workgroups per CU.
-// Contraction, operand maps, subnormal-pixel trick and packed epilogue: blend_ten.hpp / blend_ten_lds.hpp / blend_ten_persist.hpp.
+// k-loops and epilogue: blend_core.hpp (shared with blend_persist); LDS-DMA helpers: blend_ten_persist.hpp.
 // Replaces Kernels::Tensors::process<false> / Kernels::Standard::process<false> (reference src/kernels.cu:289-343, 398-461).
 #pragma once
 
@@ -114,12 +114,7 @@ __global__ void __launch_bounds__(256, 2) blend_wave(const KernelArgs a, const i
     int prev_stores = 0; // store instructions of the previous epilogue (the youngest VMEM operations of this wave)
     issue(t, 0);
 
-    // the first MFMA of a tile takes a zero C operand (an inline constant): the accumulators are never cleared
-    f32x16 acc[MT][3];
-    f32x16 zero16;
-#pragma unroll
-    for(int e = 0; e < 16; e++)
-        zero16[e] = 0.0f;
+    f32x16 acc[MT][3]; // never cleared: the first MFMA of a tile takes a zero C operand (unit_ten / unit_std, ZERO_FIRST)
 
     const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(lds);
     while(true)
@@ -143,90 +138,9 @@ __global__ void __launch_bounds__(256, 2) blend_wave(const KernelArgs a, const i
         // ---- compute the tile ------------------------------------------------------------------------------------------------
         const uint32_t *px_buf = lds + W_DW + wave * (2 * PX_DW) + buf * PX_DW;
         if constexpr(!STD)
-        {
-            const uint32_t *col = px_buf + r + 8 * h * TPX; // this lane's pixel column, first image of its k-half
-#pragma unroll
-            for(int ks = 0; ks < KS; ks++)
-            {
-                if(16 * ks < kc)
-                {
-                    half8 wfrag[MT];
-#pragma unroll
-                    for(int m = 0; m < MT; m++)
-                        wfrag[m] = __builtin_bit_cast(half8, w_buf[(2 * ks + h) * VPP + m * 32 + r]);
-                    uint32_t px[8];
-#pragma unroll
-                    for(int j = 0; j < 8; j++)
-                        px[j] = col[(16 * ks + j) * TPX];
-                    u32x4 bc[3];
-#pragma unroll
-                    for(int q = 0; q < 4; q++)
-                    {
-                        bc[0][q] = pack_subnormal_pair<0>(px[2 * q], px[2 * q + 1]);
-                        bc[1][q] = pack_subnormal_pair<1>(px[2 * q], px[2 * q + 1]);
-                        bc[2][q] = pack_subnormal_pair<2>(px[2 * q], px[2 * q + 1]);
-                    }
-#pragma unroll
-                    for(int c = 0; c < 3; c++)
-                    {
-                        const half8 bfrag = __builtin_bit_cast(half8, bc[c]);
-#pragma unroll
-                        for(int m = 0; m < MT; m++)
-                            acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[m], bfrag, ks == 0 ? zero16 : acc[m][c], 0, 0, 0);
-                    }
-                }
-            }
-        }
+            unit_ten<MT, TPX, KS, true>(px_buf + r + 8 * h * TPX, w_buf, r, h, kc, acc);
         else
-        {
-            // exact fp32 (see blend_persist): MFMA q of a k-step multiplies image pair (16ks+2q, 16ks+2q+1), ascending
-            const uint32_t *col = px_buf + r + h * TPX;
-            uint32_t px[2][8];
-            u32x4 wlo[2][MT], whi[2][MT];
-            auto load_step = [&](int ks, int slot) {
-#pragma unroll
-                for(int q = 0; q < 8; q++)
-                    px[slot][q] = col[(16 * ks + 2 * q) * TPX];
-#pragma unroll
-                for(int m = 0; m < MT; m++)
-                {
-                    wlo[slot][m] = w_buf[(2 * ks) * VPP + m * 32 + r];
-                    whi[slot][m] = w_buf[(2 * ks + 1) * VPP + m * 32 + r];
-                }
-            };
-            const uint32_t sh = 16u * uint32_t(h);
-            load_step(0, 0);
-#pragma unroll
-            for(int ks = 0; ks < KS; ks++)
-            {
-                if(16 * ks < kc)
-                {
-                    const int cur = ks & 1;
-                    if(ks + 1 < KS && 16 * (ks + 1) < kc)
-                        load_step(ks + 1, cur ^ 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for(int q = 0; q < 8; q++)
-                    {
-                        float wq[MT];
-#pragma unroll
-                        for(int m = 0; m < MT; m++)
-                        {
-                            const uint32_t d = q < 4 ? wlo[cur][m][q] : whi[cur][m][q - 4];
-                            wq[m] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(d >> sh))); // exact
-                        }
-                        const uint32_t p = px[cur][q];
-                        const float pc[3] = {static_cast<float>(p & 0xffu), static_cast<float>((p >> 8) & 0xffu),
-                                             static_cast<float>((p >> 16) & 0xffu)};
-#pragma unroll
-                        for(int c = 0; c < 3; c++)
-#pragma unroll
-                            for(int m = 0; m < MT; m++)
-                                acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[m], pc[c], (ks == 0 && q == 0) ? zero16 : acc[m][c], 0, 0, 0);
-                    }
-                }
-            }
-        }
+            unit_std<MT, TPX, KS, true>(px_buf + r + h * TPX, w_buf, r, h, kc, acc);
 
         // ---- epilogue ------------------------------------------------------------------------------------------------------------
         {
@@ -236,58 +150,7 @@ __global__ void __launch_bounds__(256, 2) blend_wave(const KernelArgs a, const i
                 __builtin_amdgcn_s_setprio(1);
             const int y = t / tiles_x; // row inside the output window
             const int xw = (t - y * tiles_x) * 128 + wave * TPX;
-            int n_st = 0; // exact count of store instructions issued below (every branch around a store is wave-uniform)
-#pragma unroll
-            for(int m = 0; m < MT; m++)
-            {
-                const int view_m = a.v0 + m * 32;
-                const int nvalid = min(a.v1 - view_m, 32); // views of this M-tile inside the launch's range
-                if(nvalid > 0)
-                {
-                    uint32_t rgba[16];
-                    if constexpr(STD)
-                        quantize_tile_rn(acc[m][0], acc[m][1], acc[m][2], rgba);
-                    else
-                        quantize_tile_packed(acc[m][0], acc[m][1], acc[m][2], rgba);
-                    uint32_t *ubase = reinterpret_cast<uint32_t *>(a.views) + (size_t)view_m * oplane_px + (size_t)y * W + xw;
-                    const uint32_t lane_off = uint32_t(r) + uint32_t(4 * h) * uint32_t(oplane_px);
-                    if(nvalid == 32 && xw + 32 <= W)
-                    {
-                        n_st += 16; // full M-tile, full run: 16 unpredicated stores
-#pragma unroll
-                        for(int e = 0; e < 16; e++)
-                        {
-                            uint32_t *out = ubase + (size_t)((e & 3) + 8 * (e >> 2)) * oplane_px + lane_off;
-                            if constexpr(NT_STORE)
-                                __builtin_nontemporal_store(rgba[e], out);
-                            else
-                                *out = rgba[e];
-                        }
-                    }
-                    else
-                    {
-                        const bool lane_x_ok = xw + r < W;
-#pragma unroll
-                        for(int e = 0; e < 16; e++)
-                        {
-                            const int vrow = (e & 3) + 8 * (e >> 2); // + 4h in lane_off
-                            if(vrow < nvalid) // wave-uniform; lane (r = 0, h = 0) is then always active, so the store is issued
-                            {
-                                n_st++;
-                                uint32_t *out = ubase + (size_t)vrow * oplane_px + lane_off;
-                                if(lane_x_ok && vrow + 4 * h < nvalid)
-                                {
-                                    if constexpr(NT_STORE)
-                                        __builtin_nontemporal_store(rgba[e], out);
-                                    else
-                                        *out = rgba[e];
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            prev_stores = n_st;
+            prev_stores = store_tile<STD, MT, NT_STORE, false>(a, acc, a.v0, y, xw, r, h, oplane_px);
             if constexpr(STD)
                 __builtin_amdgcn_s_setprio(0);
         }
