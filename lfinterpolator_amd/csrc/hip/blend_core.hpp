@@ -73,12 +73,14 @@ __device__ __forceinline__ void unit_ten(const uint32_t *col, const u32x4 *w_buf
 
 // STD k-loop of one unit, exact fp32: MFMA q of a k-step multiplies image pair (16ks+2q, 16ks+2q+1): k = 0 ↔ lower half-wave,
 // k = 1 ↔ upper, accumulated in that order = the reference's ascending-g fmaf chain (src/kernels.cu:328-338).
-// col = this lane's pixel column at image h.  Raw LDS words of one k-step: this half-wave's 8 pixels (images 2q + h) and this
-// lane's view row of the fp16 weights for the 16 images (two octets; image 2q+h sits in bits [16h, 16h+16) of dword q).  The
-// reads of k-step ks+1 are issued BEFORE the 48 MFMAs of k-step ks (register double buffer, scheduling barrier), so the
-// matrix pipe never waits for LDS latency inside the loop.
-template <int MT, int TPX, int KS, bool ZERO_FIRST>
-__device__ __forceinline__ void unit_std(const uint32_t *col, const u32x4 *w_buf, const int r, const int h, const int kc,
+// col = this lane's pixel column at image h.  Weights, W32 = false: the fp16 fragments of the TEN_WM layout, this lane's view
+// row of a k-step's 16 images in two octets (image 2q+h sits in bits [16h, 16h+16) of dword q), widened on the fly (exact);
+// W32 = true: f32 weights [image][VPP views] (widened once per workgroup), one ds_read_b32 per operand and no conversion —
+// on this path every VALU instruction is a cycle group the fp32 matrix instruction does not get (same FMA lanes).
+// The LDS reads of k-step ks+1 are issued BEFORE the 48 MFMAs of k-step ks (register double buffer, scheduling barrier), so
+// the matrix pipe never waits for LDS latency inside the loop.
+template <int MT, int TPX, int KS, bool ZERO_FIRST, bool W32 = false>
+__device__ __forceinline__ void unit_std(const uint32_t *col, const void *weights, const int r, const int h, const int kc,
                                          f32x16 (&acc)[MT][3])
 {
     constexpr int VPP = MT * 32;
@@ -86,17 +88,31 @@ __device__ __forceinline__ void unit_std(const uint32_t *col, const u32x4 *w_buf
 #pragma unroll
     for(int e = 0; e < 16; e++)
         zero16[e] = 0.0f;
+    const u32x4 *w_buf = static_cast<const u32x4 *>(weights);
+    const float *wf = static_cast<const float *>(weights) + h * VPP + r; // W32: this lane's view column at image h
     uint32_t px[2][8];
     u32x4 wlo[2][MT], whi[2][MT];
+    float w32[2][8][MT];
     auto load_step = [&](int ks, int slot) {
 #pragma unroll
         for(int q = 0; q < 8; q++)
             px[slot][q] = col[(16 * ks + 2 * q) * TPX];
-#pragma unroll
-        for(int m = 0; m < MT; m++)
+        if constexpr(W32)
         {
-            wlo[slot][m] = w_buf[(2 * ks) * VPP + m * 32 + r];
-            whi[slot][m] = w_buf[(2 * ks + 1) * VPP + m * 32 + r];
+#pragma unroll
+            for(int q = 0; q < 8; q++)
+#pragma unroll
+                for(int m = 0; m < MT; m++)
+                    w32[slot][q][m] = wf[(16 * ks + 2 * q) * VPP + m * 32];
+        }
+        else
+        {
+#pragma unroll
+            for(int m = 0; m < MT; m++)
+            {
+                wlo[slot][m] = w_buf[(2 * ks) * VPP + m * 32 + r];
+                whi[slot][m] = w_buf[(2 * ks + 1) * VPP + m * 32 + r];
+            }
         }
     };
     const uint32_t sh = 16u * uint32_t(h);
@@ -117,8 +133,13 @@ __device__ __forceinline__ void unit_std(const uint32_t *col, const u32x4 *w_buf
 #pragma unroll
                 for(int m = 0; m < MT; m++)
                 {
-                    const uint32_t d = q < 4 ? wlo[cur][m][q] : whi[cur][m][q - 4];
-                    wq[m] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(d >> sh))); // exact
+                    if constexpr(W32)
+                        wq[m] = w32[cur][q][m];
+                    else
+                    {
+                        const uint32_t d = q < 4 ? wlo[cur][m][q] : whi[cur][m][q - 4];
+                        wq[m] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(d >> sh))); // exact
+                    }
                 }
                 const uint32_t p = px[cur][q];
                 const float pc[3] = {static_cast<float>(p & 0xffu), static_cast<float>((p >> 8) & 0xffu),
@@ -154,15 +175,17 @@ __device__ __forceinline__ int store_tile(const KernelArgs &a, f32x16 (&acc)[MT]
                 quantize_tile_rn(acc[m][0], acc[m][1], acc[m][2], rgba);
             else
                 quantize_tile_packed(acc[m][0], acc[m][1], acc[m][2], rgba);
-            uint32_t *ubase = reinterpret_cast<uint32_t *>(a.views) + (size_t)view_m * oplane_px + (size_t)y * W + xw;
-            const uint32_t lane_off = uint32_t(r) + uint32_t(4 * h) * uint32_t(oplane_px);
+            // wave-uniform 64-bit base per store + one 32-bit per-lane byte offset (4 views × a plane < 4 GB): no per-store
+            // vector address arithmetic
+            uint8_t *ubase = a.views + ((size_t)view_m * oplane_px + (size_t)y * W + xw) * 4;
+            const uint32_t lane_off = (uint32_t(r) + uint32_t(4 * h) * uint32_t(oplane_px)) * 4u;
             if(nvalid == 32 && xw + 32 <= W)
             {
                 n_st += 16; // full M-tile, full run: 16 unpredicated stores
 #pragma unroll
                 for(int e = 0; e < 16; e++)
                 {
-                    uint32_t *out = ubase + (size_t)((e & 3) + 8 * (e >> 2)) * oplane_px + lane_off;
+                    uint32_t *out = reinterpret_cast<uint32_t *>(ubase + (size_t)((e & 3) + 8 * (e >> 2)) * oplane_px * 4 + lane_off);
                     if constexpr(NT_STORE)
                         __builtin_nontemporal_store(rgba[e], out);
                     else
@@ -179,7 +202,7 @@ __device__ __forceinline__ int store_tile(const KernelArgs &a, f32x16 (&acc)[MT]
                     if(vrow < nvalid) // wave-uniform; lane (r = 0, h = 0) is then always active, so the store is issued
                     {
                         n_st++;
-                        uint32_t *out = ubase + (size_t)vrow * oplane_px + lane_off;
+                        uint32_t *out = reinterpret_cast<uint32_t *>(ubase + (size_t)vrow * oplane_px * 4 + lane_off);
                         if(lane_x_ok && vrow + 4 * h < nvalid)
                         {
                             if constexpr(NT_STORE)

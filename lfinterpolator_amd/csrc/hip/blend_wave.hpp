@@ -14,7 +14,8 @@
 //                            compute the tile from LDS (same operand maps as blend_persist)
 //                            epilogue + 32 stores
 //
-// LDS: 8 KB weight fragments + 4 waves × 2 × 8 KB = 72 KB per workgroup, two workgroups per CU.
+// LDS: 8 KB (TEN_WM, fp16 fragments) or 16 KB (STD, f32) of weights + 4 waves × 2 × 8 KB = 72 / 80 KB per workgroup, two
+// workgroups per CU.
 // k-loops and epilogue: blend_core.hpp (shared with blend_persist); LDS-DMA helpers: blend_ten_persist.hpp.
 // Replaces Kernels::Tensors::process<false> / Kernels::Standard::process<false> (reference src/kernels.cu:289-343, 398-461).
 #pragma once
@@ -27,7 +28,8 @@ template <bool STD, int MT, bool NT_STORE>
 __global__ void __launch_bounds__(256, 2) blend_wave(const KernelArgs a, const int tiles_x, const int n_tiles)
 {
     constexpr int KC = 64, KS = KC / 16, VPP = MT * 32, TPX = 32;
-    constexpr int W_DW = (KC / 8) * VPP * 4; // weight fragments [k-octet][view] × 16 B
+    // weights: TEN_WM the fp16 fragments [k-octet][view] × 16 B (8 KB); STD f32 [image][view] (16 KB, no conversions in the k-loop)
+    constexpr int W_DW = STD ? KC * VPP : (KC / 8) * VPP * 4;
     constexpr int PX_DW = KC * TPX;          // one pixel buffer of one wave
     __shared__ __attribute__((aligned(16))) uint32_t lds[W_DW + 4 * 2 * PX_DW];
 
@@ -43,13 +45,26 @@ __global__ void __launch_bounds__(256, 2) blend_wave(const KernelArgs a, const i
     const int kc = a.k_pad; // ≤ KC (host)
 
     // ---- once per workgroup: the weight fragments (as blend_persist's issue(), all four waves) ---------------------------
-    for(int o = wave; 8 * o < kc; o += 4)
-        if(lane < VPP)
-            dma16((STD ? a.w16 : a.w16s) + (size_t)(a.v0 + lane) * a.k_pad + 8 * o, lds_base + uint32_t(o) * (VPP * 16));
+    if constexpr(STD)
+    {
+        // rows of the transposed f32 copy (w32t[image][v_pad]): 16 lanes × 16 B = one image's VPP = 64 views, 4 images per piece
+        static_assert(!STD || MT == 2, "the f32 weight copy below assumes 64 views per pass");
+        for(int k4 = wave; 4 * k4 < kc; k4 += 4)
+            dma16(a.w32t + (size_t)(4 * k4 + (lane >> 4)) * a.v_pad + a.v0 + 4 * (lane & 15), lds_base + uint32_t(k4) * 1024u);
+    }
+    else
+    {
+        for(int o = wave; 8 * o < kc; o += 4)
+            if(lane < VPP)
+                dma16(a.w16s + (size_t)(a.v0 + lane) * a.k_pad + 8 * o, lds_base + uint32_t(o) * (VPP * 16));
+    }
 
-    // ---- per lane, once: the integer offsets of the image this lane fetches in each of the 8 DMA pieces ---------------------
+    // ---- per lane, once: the image this lane fetches in each of the 8 DMA pieces, its integer offsets, and the element offset
+    // of its 16 bytes for the tile at (0, 0) — for tiles whose every sample is inside the image (wave-uniform test against
+    // the bounds of the offsets) a piece's address is that constant plus one wave-uniform tile term.
     // piece i moves images 8i … 8i+7, eight lanes (16 B = 4 pixels each) per image: lane l ↔ image 8i + (l >> 3), pixels 4(l & 7)…
     int ox[8], oy[8], gi[8];
+    int64_t lane_elem[8];
 #pragma unroll
     for(int i = 0; i < 8; i++)
     {
@@ -57,16 +72,26 @@ __global__ void __launch_bounds__(256, 2) blend_wave(const KernelArgs a, const i
         const lfi_int2 o = a.focused[gi[i]];
         ox[i] = o.x;
         oy[i] = o.y;
+        lane_elem[i] = (int64_t)gi[i] * (int64_t)plane_px + (int64_t)(o.y - a.in_y0) * W + o.x + 4 * (lane & 7);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier(); // the only one: weights in LDS
     asm volatile("" ::: "memory");
 
-    auto issue = [&](const int t, const int buf) {
-        const int ty = t / tiles_x;
+    // tile (tx, ty) of the 128-pixel tile grid; this wave's 32 pixels start at column 128 tx + 32 wave of output row ty
+    auto issue = [&](const int tx, const int ty, const int buf) {
         const int y = a.out_y0 + ty; // global row
-        const int xw = (t - ty * tiles_x) * 128 + wave * TPX;
+        const int xw = tx * 128 + wave * TPX;
         const uint32_t dst = px_base + uint32_t(buf) * (PX_DW * 4);
+        if(xw + a.fo_min_x >= 0 && xw + TPX + a.fo_max_x <= W && y + a.fo_min_y >= 0 && y + a.fo_max_y <= H - 1)
+        {
+            const uint32_t *tile = grid32 + ((size_t)y * W + xw); // wave-uniform
+#pragma unroll
+            for(int i = 0; i < 8; i++)
+                if(8 * i < kc)
+                    dma16(tile + lane_elem[i], dst + uint32_t(i) * 1024u);
+            return;
+        }
 #pragma unroll
         for(int i = 0; i < 8; i++)
         {
@@ -96,30 +121,40 @@ __global__ void __launch_bounds__(256, 2) blend_wave(const KernelArgs a, const i
         }
     };
 
-    // ---- this workgroup's tiles j, j+G, j+2G …; a wave whose 32 pixels start beyond the row's end skips the tile ------------
+    // ---- this workgroup's tiles j, j+G, j+2G … as (tx, ty), advanced without divisions; a wave whose 32 pixels start beyond
+    // the row's end skips the tile ------------------------------------------------------------------------------------------
     const int G = gridDim.x;
-    auto has_pixels = [&](const int t) { return (t % tiles_x) * 128 + wave * TPX < W; };
-    auto next_tile = [&](int t) {
+    const int step_y = G / tiles_x, step_x = G - step_y * tiles_x;
+    const int rows_out = n_tiles / tiles_x;
+    auto advance = [&](int &tx, int &ty) {
         do
-            t += G;
-        while(t < n_tiles && !has_pixels(t));
-        return t;
+        {
+            tx += step_x;
+            ty += step_y;
+            if(tx >= tiles_x)
+            {
+                tx -= tiles_x;
+                ty++;
+            }
+        } while(ty < rows_out && tx * 128 + wave * TPX >= W);
     };
-    int t = int(xcd_contiguous(blockIdx.x, gridDim.x));
-    if(t < n_tiles && !has_pixels(t))
-        t = next_tile(t);
-    if(t >= n_tiles)
+    const int t0 = int(xcd_contiguous(blockIdx.x, gridDim.x));
+    int ty = t0 / tiles_x, tx = t0 - ty * tiles_x;
+    if(ty < rows_out && tx * 128 + wave * TPX >= W)
+        advance(tx, ty);
+    if(ty >= rows_out)
         return;
     int buf = 0;
     int prev_stores = 0; // store instructions of the previous epilogue (the youngest VMEM operations of this wave)
-    issue(t, 0);
+    issue(tx, ty, 0);
 
     f32x16 acc[MT][3]; // never cleared: the first MFMA of a tile takes a zero C operand (unit_ten / unit_std, ZERO_FIRST)
 
     const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(lds);
     while(true)
     {
-        const int nt = next_tile(t);
+        int ntx = tx, nty = ty;
+        advance(ntx, nty);
         // this wave's pieces of the current tile have landed; the previous epilogue's stores may still be in flight (vmcnt
         // retires in order and the stores are the youngest operations)
         if(prev_stores >= 32)
@@ -132,15 +167,15 @@ __global__ void __launch_bounds__(256, 2) blend_wave(const KernelArgs a, const i
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if(nt < n_tiles)
-            issue(nt, buf ^ 1); // this wave finished reading that buffer one tile ago (program order)
+        if(nty < rows_out)
+            issue(ntx, nty, buf ^ 1); // this wave finished reading that buffer one tile ago (program order)
 
         // ---- compute the tile ------------------------------------------------------------------------------------------------
         const uint32_t *px_buf = lds + W_DW + wave * (2 * PX_DW) + buf * PX_DW;
         if constexpr(!STD)
             unit_ten<MT, TPX, KS, true>(px_buf + r + 8 * h * TPX, w_buf, r, h, kc, acc);
         else
-            unit_std<MT, TPX, KS, true>(px_buf + r + h * TPX, w_buf, r, h, kc, acc);
+            unit_std<MT, TPX, KS, true, true>(px_buf + r + h * TPX, lds, r, h, kc, acc);
 
         // ---- epilogue ------------------------------------------------------------------------------------------------------------
         {
@@ -148,15 +183,14 @@ __global__ void __launch_bounds__(256, 2) blend_wave(const KernelArgs a, const i
             // under the other wave's MFMAs and be over quickly, not take the issue slots that wave leaves (measured −3 %)
             if constexpr(STD)
                 __builtin_amdgcn_s_setprio(1);
-            const int y = t / tiles_x; // row inside the output window
-            const int xw = (t - y * tiles_x) * 128 + wave * TPX;
-            prev_stores = store_tile<STD, MT, NT_STORE, false>(a, acc, a.v0, y, xw, r, h, oplane_px);
+            prev_stores = store_tile<STD, MT, NT_STORE, false>(a, acc, a.v0, ty, tx * 128 + wave * TPX, r, h, oplane_px);
             if constexpr(STD)
                 __builtin_amdgcn_s_setprio(0);
         }
-        if(nt >= n_tiles)
+        if(nty >= rows_out)
             break;
-        t = nt;
+        tx = ntx;
+        ty = nty;
         buf ^= 1;
     }
 }

@@ -46,6 +46,7 @@ struct KernelArgs
     int32_t v0, v1;                         // view range of this launch
     int32_t n_focus_ids;
     int32_t radius_x, radius_y;             // constants[9..10]
+    int32_t fo_min_x, fo_max_x, fo_min_y, fo_max_y; // bounds of focusedOffsets over the n_images images (interior-tile tests)
     int32_t map_index;                      // which focus map an all-focus render reads
     float focus, range;                     // inFocus, inRange
     uint32_t flags;

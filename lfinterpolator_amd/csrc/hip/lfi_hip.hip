@@ -76,6 +76,7 @@ struct lfi_ctx
     int32_t *d_ids = nullptr;
     float focus = 0, range = 0;
     int radius[2] = {1, 1};
+    int fo_min[2] = {0, 0}, fo_max[2] = {0, 0}; // bounds of the integer offsets
     uint32_t flags = 0;
     float *prequant = nullptr;
     std::vector<lfi_float2> h_focus_offsets; // offsets of the focus_map_ids images (host copy: sizes the padded planes)
@@ -153,6 +154,10 @@ KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
     a.v0 = v0;
     a.v1 = v1;
     a.n_focus_ids = c->n_focus_ids;
+    a.fo_min_x = c->fo_min[0];
+    a.fo_max_x = c->fo_max[0];
+    a.fo_min_y = c->fo_min[1];
+    a.fo_max_y = c->fo_max[1];
     a.radius_x = c->radius[0];
     a.radius_y = c->radius[1];
     // the reference reads map 1 in Standard::process and map 0 in Tensors::process (src/kernels.cu:326 vs :430);
@@ -883,6 +888,14 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     const size_t total = off_ids + sizeof(int32_t) * LFI_MAX_FOCUS_IDS;
     std::vector<uint8_t> blob(total, 0);
     std::memcpy(blob.data() + off_focused, p->focused_offsets, sizeof(lfi_int2) * n);
+    int fo_min[2] = {p->focused_offsets[0].x, p->focused_offsets[0].y}, fo_max[2] = {fo_min[0], fo_min[1]};
+    for(int g = 1; g < n; g++)
+    {
+        fo_min[0] = std::min(fo_min[0], p->focused_offsets[g].x);
+        fo_max[0] = std::max(fo_max[0], p->focused_offsets[g].x);
+        fo_min[1] = std::min(fo_min[1], p->focused_offsets[g].y);
+        fo_max[1] = std::max(fo_max[1], p->focused_offsets[g].y);
+    }
     std::memcpy(blob.data() + off_offsets, p->offsets, sizeof(lfi_float2) * n);
     uint16_t *w16 = reinterpret_cast<uint16_t *>(blob.data() + off_w16);
     uint16_t *w16s = reinterpret_cast<uint16_t *>(blob.data() + off_w16s);
@@ -927,6 +940,11 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
         ctx->h_focus_offsets.push_back(p->offsets[p->focus_map_ids[k]]);
     ctx->focus = p->focus;
     ctx->range = p->range;
+    for(int d = 0; d < 2; d++)
+    {
+        ctx->fo_min[d] = fo_min[d];
+        ctx->fo_max[d] = fo_max[d];
+    }
     ctx->radius[0] = std::max(p->block_radius[0], 1);
     ctx->radius[1] = std::max(p->block_radius[1], 1);
     ctx->flags = p->flags;
