@@ -83,3 +83,31 @@ def test_full_size_properties(cfg, gpu, oracle_c):
     ctx.sync()
     assert (ctx.download_view(V // 2) == ten_views[V // 2]).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 1920, 1080), (15, 15, 3840, 2160)], ids=["8x8_1080p", "15x15_4k"])
+def test_focus_map_full_size_variants_agree(shape, gpu):
+    """The focus map at BASELINE's sizes (config 5's all-focus parameters): the factored estimate (range images, line images
+    for flagged rows / columns, tap-by-tap keys for the rest) and the LDS-staged kernel — independent implementations, each
+    checked against the oracle at small sizes — must produce identical maps, and the all-focus render must read them."""
+    cols, rows, W, H = shape
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.fill_synthetic(SEED)
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.22, 0.17, 7.0, 1.783, 8)
+    ctx.set_params(hp)
+    maps = {}
+    for variant in ("factored", "lds"):
+        ctx.set_variant("FOCUS", variant)
+        ctx.focus_map()
+        ctx.focus_map()   # a second call reuses the workspace and the side stream
+        ctx.sync()
+        maps[variant] = (ctx.download_map(0), ctx.download_map(1))
+    assert (maps["factored"][0] == maps["lds"][0]).all(), int((maps["factored"][0] != maps["lds"][0]).sum())
+    assert (maps["factored"][1] == maps["lds"][1]).all()
+    assert len(np.unique(maps["factored"][0][..., 0])) > 4
+    ctx.set_variant("FOCUS", "auto")
+    ctx.render("TEN_WM", all_focus=True)
+    ctx.render("STD", all_focus=True)
+    ctx.sync()
+    ctx.close()
