@@ -495,16 +495,11 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     }
     hipStream_t st = ctx->stream;
     hipStream_t aux = ctx->aux_stream;
+    // host launch order = the critical path first: the main stream's kernels are enqueued before the side stream's
     hipLaunchKernelGGL(lfi::focus_plan_shifts, dim3(1), dim3(1024), 0, st, a, w);
     LFI_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
-    LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_fork, 0));
-    LFI_HIP(ctx, hipMemsetAsync(w.badx, 0, o_cols - o_badx, aux)); // badx and bady are adjacent
-    hipLaunchKernelGGL(lfi::focus_plan_flags, dim3((std::max(W, H) + 255) / 256, lfi::FOCUS_STEPS, 2), dim3(256), 0, aux, a, w);
-    hipLaunchKernelGGL(lfi::focus_plan_lists, dim3(lfi::FOCUS_STEPS, 2), dim3(64), 0, aux, a, w);
-    hipLaunchKernelGGL(lfi::focus_plan_prefix, dim3(1), dim3(1), 0, aux, a, w);
     hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, ctx->n_focus_ids), dim3(64), 0, st, a, w);
     LFI_HIP(ctx, hipEventRecord(ctx->ev_pad, st));
-    LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_pad, 0));
     const uint32_t tiles_x = uint32_t(w.We_p / 256), tiles_y = uint32_t(w.He_p / 4);
     {
         constexpr int CPW = 4, GROUPS = lfi::FOCUS_STEPS / CPW;
@@ -512,6 +507,12 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
         const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(tiles_x, tiles_y, GROUPS) : tiles_x * tiles_y * GROUPS;
         hipLaunchKernelGGL(lfi::focus_range<CPW>, dim3(nblocks), dim3(256), 0, st, a, w, nblocks, striped);
     }
+    LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_fork, 0));
+    LFI_HIP(ctx, hipMemsetAsync(w.badx, 0, o_cols - o_badx, aux)); // badx and bady are adjacent
+    hipLaunchKernelGGL(lfi::focus_plan_flags, dim3((std::max(W, H) + 255) / 256, lfi::FOCUS_STEPS, 2), dim3(256), 0, aux, a, w);
+    hipLaunchKernelGGL(lfi::focus_plan_lists, dim3(lfi::FOCUS_STEPS, 2), dim3(64), 0, aux, a, w);
+    hipLaunchKernelGGL(lfi::focus_plan_prefix, dim3(1), dim3(1), 0, aux, a, w);
+    LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_pad, 0));
     {
         const uint32_t per_pass = uint32_t(ctx->cu_count) * 4u / 8u * 8u;
         hipLaunchKernelGGL(lfi::focus_flagged, dim3(3 * per_pass), dim3(256), 0, aux, a, w, per_pass);
