@@ -13,6 +13,9 @@ maps = {"constant": np.full((H, W), 128, np.uint8),
         "smooth gradient": ((xx / W * 255)).astype(np.uint8),
         "piecewise (64px blocks)": (((xx // 64) * 37 + (yy // 64) * 91) % 256).astype(np.uint8),
         "random": np.random.default_rng(0).integers(0, 256, (H, W), dtype=np.uint8)}
+variants = dict(v.split("=") for v in sys.argv[1:])   # e.g. TEN_WM=wave_m2_nt STD=persist_m2_nt
+for meth, var in variants.items():
+    ctx.set_variant(meth, var)
 for name, mv in maps.items():
     ctx.upload_map(1, map_of(mv))
     out = []
