@@ -1,5 +1,5 @@
 // image_io.cpp — RGBA8 image files for LfLoader / storeResults, on zlib (the reference vendors stb_image v2.27 and
-// stb_image_write v1.16 for this: reference src/lfLoader.cpp:33-42, src/interpolator.cu:313).  Reads non-interlaced PNG
+// stb_image_write v1.16 for this: reference src/lfLoader.cpp:33-42, src/interpolator.cu:313).  Reads PNG (also Adam7-interlaced)
 // (grey, grey+alpha, RGB, RGBA, palette; 1–16 bit) and binary PPM/PGM; writes 8-bit RGBA/RGB PNG and PPM.
 #include "image_io.h"
 
@@ -85,8 +85,8 @@ Image decodePng(const std::vector<uint8_t> &file, const std::string &path)
     }
     if(width == 0 || height == 0 || width > (1u << 15) || height > (1u << 15))
         throw bad("bad dimensions");
-    if(interlace != 0)
-        throw bad("interlaced PNG is not supported");
+    if(interlace > 1)
+        throw bad("bad interlace method");
     int channels;
     switch(colorType)
     {
@@ -100,37 +100,37 @@ Image decodePng(const std::vector<uint8_t> &file, const std::string &path)
     if(!(depth == 8 || depth == 16 || ((colorType == 0 || colorType == 3) && (depth == 1 || depth == 2 || depth == 4))))
         throw bad("bad bit depth");
     const size_t bitsPerPixel = size_t(channels) * depth;
-    const size_t stride = (size_t(width) * bitsPerPixel + 7) / 8;
     const size_t bpp = std::max<size_t>(1, bitsPerPixel / 8);
-    std::vector<uint8_t> raw((stride + 1) * height);
+    // the image is one pass, or the seven Adam7 passes one after the other (each a small image of its own)
+    struct Pass
+    {
+        uint32_t x0, y0, dx, dy, w, h;
+        size_t stride;
+    };
+    std::vector<Pass> passes;
+    if(interlace == 0)
+        passes.push_back({0, 0, 1, 1, width, height, 0});
+    else
+    {
+        static const uint32_t X0[7] = {0, 4, 0, 2, 0, 1, 0}, Y0[7] = {0, 0, 4, 0, 2, 0, 1};
+        static const uint32_t DX[7] = {8, 8, 4, 4, 2, 2, 1}, DY[7] = {8, 8, 8, 4, 4, 2, 2};
+        for(int i = 0; i < 7; i++)
+        {
+            const uint32_t w = (width + DX[i] - 1 - X0[i]) / DX[i], h = (height + DY[i] - 1 - Y0[i]) / DY[i];
+            if(width > X0[i] && height > Y0[i] && w && h)
+                passes.push_back({X0[i], Y0[i], DX[i], DY[i], w, h, 0});
+        }
+    }
+    size_t rawBytes = 0;
+    for(Pass &ps : passes)
+    {
+        ps.stride = (size_t(ps.w) * bitsPerPixel + 7) / 8;
+        rawBytes += (ps.stride + 1) * ps.h;
+    }
+    std::vector<uint8_t> raw(rawBytes);
     uLongf rawSize = raw.size();
     if(uncompress(raw.data(), &rawSize, idat.data(), idat.size()) != Z_OK || rawSize != raw.size())
         throw bad("corrupt image data");
-
-    // undo the per-row filters in place
-    std::vector<uint8_t> prior(stride, 0);
-    for(uint32_t y = 0; y < height; y++)
-    {
-        uint8_t *row = &raw[y * (stride + 1)];
-        const uint8_t filter = row[0];
-        uint8_t *cur = row + 1;
-        for(size_t i = 0; i < stride; i++)
-        {
-            const int a = i >= bpp ? cur[i - bpp] : 0, b = prior[i], c = i >= bpp ? prior[i - bpp] : 0;
-            int v = cur[i];
-            switch(filter)
-            {
-                case 0: break;
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) / 2; break;
-                case 4: v += paeth(a, b, c); break;
-                default: throw bad("bad filter");
-            }
-            cur[i] = uint8_t(v);
-        }
-        std::memcpy(prior.data(), cur, stride);
-    }
 
     Image img;
     img.width = int(width);
@@ -144,55 +144,85 @@ Image decodePng(const std::vector<uint8_t> &file, const std::string &path)
         const size_t bit = index * depth;
         return (cur[bit / 8] >> (8 - depth - bit % 8)) & ((1u << depth) - 1u);
     };
-    for(uint32_t y = 0; y < height; y++)
+    uint8_t *passData = raw.data();
+    for(const Pass &ps : passes)
     {
-        const uint8_t *cur = &raw[y * (stride + 1) + 1];
-        uint8_t *out = &img.pixels[size_t(y) * width * 4];
-        for(uint32_t x = 0; x < width; x++, out += 4)
+        const size_t stride = ps.stride;
+        // undo the per-row filters in place
+        std::vector<uint8_t> prior(stride, 0);
+        for(uint32_t y = 0; y < ps.h; y++)
         {
-            switch(colorType)
+            uint8_t *row = passData + y * (stride + 1);
+            const uint8_t filter = row[0];
+            uint8_t *cur = row + 1;
+            for(size_t i = 0; i < stride; i++)
             {
-                case 0:
+                const int a = i >= bpp ? cur[i - bpp] : 0, b = prior[i], c = i >= bpp ? prior[i - bpp] : 0;
+                int v = cur[i];
+                switch(filter)
                 {
-                    uint32_t v = sample(cur, x);
-                    const bool keyed = transparency.size() >= 2 && (depth == 16 ? cur[2 * x] == transparency[0] && cur[2 * x + 1] == transparency[1] : v == transparency[1]);
-                    if(depth < 8)
-                        v = v * 255 / ((1u << depth) - 1u);
-                    out[0] = out[1] = out[2] = uint8_t(v);
-                    out[3] = keyed ? 0 : 255;
-                    break;
+                    case 0: break;
+                    case 1: v += a; break;
+                    case 2: v += b; break;
+                    case 3: v += (a + b) / 2; break;
+                    case 4: v += paeth(a, b, c); break;
+                    default: throw bad("bad filter");
                 }
-                case 2:
-                    out[0] = uint8_t(sample(cur, 3 * x));
-                    out[1] = uint8_t(sample(cur, 3 * x + 1));
-                    out[2] = uint8_t(sample(cur, 3 * x + 2));
-                    out[3] = 255;
-                    if(depth == 8 && transparency.size() >= 6 && out[0] == transparency[1] && out[1] == transparency[3] && out[2] == transparency[5])
-                        out[3] = 0;
-                    break;
-                case 3:
+                cur[i] = uint8_t(v);
+            }
+            std::memcpy(prior.data(), cur, stride);
+        }
+        for(uint32_t y = 0; y < ps.h; y++)
+        {
+            const uint8_t *cur = passData + y * (stride + 1) + 1;
+            for(uint32_t x = 0; x < ps.w; x++)
+            {
+                uint8_t *out = &img.pixels[(size_t(ps.y0 + y * ps.dy) * width + (ps.x0 + x * ps.dx)) * 4];
+                switch(colorType)
                 {
-                    const uint32_t idx = sample(cur, x);
-                    if(size_t(idx) * 3 + 2 >= palette.size())
-                        throw bad("palette index out of range");
-                    out[0] = palette[idx * 3];
-                    out[1] = palette[idx * 3 + 1];
-                    out[2] = palette[idx * 3 + 2];
-                    out[3] = idx < transparency.size() ? transparency[idx] : 255;
-                    break;
+                    case 0:
+                    {
+                        uint32_t v = sample(cur, x);
+                        const bool keyed = transparency.size() >= 2 && (depth == 16 ? cur[2 * x] == transparency[0] && cur[2 * x + 1] == transparency[1] : v == transparency[1]);
+                        if(depth < 8)
+                            v = v * 255 / ((1u << depth) - 1u);
+                        out[0] = out[1] = out[2] = uint8_t(v);
+                        out[3] = keyed ? 0 : 255;
+                        break;
+                    }
+                    case 2:
+                        out[0] = uint8_t(sample(cur, 3 * x));
+                        out[1] = uint8_t(sample(cur, 3 * x + 1));
+                        out[2] = uint8_t(sample(cur, 3 * x + 2));
+                        out[3] = 255;
+                        if(depth == 8 && transparency.size() >= 6 && out[0] == transparency[1] && out[1] == transparency[3] && out[2] == transparency[5])
+                            out[3] = 0;
+                        break;
+                    case 3:
+                    {
+                        const uint32_t idx = sample(cur, x);
+                        if(size_t(idx) * 3 + 2 >= palette.size())
+                            throw bad("palette index out of range");
+                        out[0] = palette[idx * 3];
+                        out[1] = palette[idx * 3 + 1];
+                        out[2] = palette[idx * 3 + 2];
+                        out[3] = idx < transparency.size() ? transparency[idx] : 255;
+                        break;
+                    }
+                    case 4:
+                        out[0] = out[1] = out[2] = uint8_t(sample(cur, 2 * x));
+                        out[3] = uint8_t(sample(cur, 2 * x + 1));
+                        break;
+                    default:
+                        out[0] = uint8_t(sample(cur, 4 * x));
+                        out[1] = uint8_t(sample(cur, 4 * x + 1));
+                        out[2] = uint8_t(sample(cur, 4 * x + 2));
+                        out[3] = uint8_t(sample(cur, 4 * x + 3));
+                        break;
                 }
-                case 4:
-                    out[0] = out[1] = out[2] = uint8_t(sample(cur, 2 * x));
-                    out[3] = uint8_t(sample(cur, 2 * x + 1));
-                    break;
-                default:
-                    out[0] = uint8_t(sample(cur, 4 * x));
-                    out[1] = uint8_t(sample(cur, 4 * x + 1));
-                    out[2] = uint8_t(sample(cur, 4 * x + 2));
-                    out[3] = uint8_t(sample(cur, 4 * x + 3));
-                    break;
             }
         }
+        passData += (stride + 1) * ps.h;
     }
     return img;
 }

@@ -90,3 +90,91 @@ def test_loader_grid_order_and_errors(native, tmp_path):
     os.remove(d / "01_02.png")
     with pytest.raises(RuntimeError, match="missing"):
         native.load_grid(str(d))
+
+
+# ---- against the reference's own codec (oracle/_ref/libref_codec.so = stb_image / stb_image_write built from the reference
+# tree by `make -C oracle ref`): what the reference's LfLoader would have handed to its kernels, pixel for pixel -------------
+def _ref_codec():
+    from oracle import ref_codec
+    if not ref_codec.available():
+        pytest.skip("oracle/_ref/libref_codec.so not built (needs /root/reference)")
+    return ref_codec
+
+
+def _png_cases(tmp_path):
+    rng = np.random.default_rng(11)
+    y, x = np.mgrid[0:29, 0:45]
+    grad = np.stack([(x * 5) % 256, (y * 7) % 256, ((x + 2 * y) * 3) % 256, 255 - (x * 4) % 256], -1).astype(np.uint8)
+    cases = {}
+    cases["rgba"] = Image.fromarray(grad, "RGBA")
+    cases["rgb"] = Image.fromarray(grad[..., :3], "RGB")
+    cases["grey"] = Image.fromarray(grad[..., 0], "L")
+    cases["grey_alpha"] = Image.fromarray(grad[..., [0, 3]], "LA")
+    pal = Image.fromarray((grad[..., 0] // 4).astype(np.uint8), "P")
+    pal.putpalette(list(rng.integers(0, 256, 768, dtype=np.uint8)))
+    cases["palette"] = pal
+    cases["grey16"] = Image.fromarray((np.arange(29 * 45, dtype=np.uint16).reshape(29, 45) * 47), "I;16")
+    cases["bilevel"] = Image.fromarray(((x + y) % 3 == 0).astype(np.uint8) * 255, "L").convert("1")
+    paths = {}
+    for name, img in cases.items():
+        p = str(tmp_path / f"{name}.png")
+        img.save(p)
+        paths[name] = p
+    # palette with per-entry alpha (tRNS) and RGB with a colour key (tRNS)
+    p = str(tmp_path / "palette_trns.png")
+    pal.save(p, transparency=bytes(rng.integers(0, 256, 64, dtype=np.uint8)))
+    paths["palette_trns"] = p
+    p = str(tmp_path / "rgb_colourkey.png")
+    Image.fromarray(grad[..., :3] // 64 * 64, "RGB").save(p, transparency=(64, 128, 0))
+    paths["rgb_colourkey"] = p
+    return paths
+
+
+def test_png_decode_matches_reference_codec(native, tmp_path):
+    ref = _ref_codec()
+    for name, path in _png_cases(tmp_path).items():
+        want = ref.load_rgba(path)
+        got = native.load_image(path)
+        assert got.shape == want.shape, name
+        assert (got == want).all(), (name, int((got != want).sum()))
+
+
+def test_png_writers_round_trip_through_each_other(native, tmp_path):
+    ref = _ref_codec()
+    arr = _rand(31, 47, 4, 5)
+    ours = str(tmp_path / "ours.png")
+    native.write_png(ours, arr)
+    assert (ref.load_rgba(ours) == arr).all()          # the reference's decoder reads our files
+    theirs = str(tmp_path / "theirs.png")
+    ref.write_png(theirs, arr)
+    assert (native.load_image(theirs) == arr).all()    # we read what stbi_write_png (src/interpolator.cu:313) writes
+
+
+def _adam7_png(arr):
+    """An Adam7-interlaced 8-bit RGB(A) PNG of arr (Pillow cannot write one): seven reduced images, filter type 0."""
+    import struct
+    import zlib
+    h, w, c = arr.shape
+    raw = b""
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = arr[y0::dy, x0::dx]
+        if sub.size:
+            raw += b"".join(b"\x00" + row.tobytes() for row in sub)
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, 6 if c == 4 else 2, 0, 0, 1)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("shape", [(37, 53, 4), (5, 3, 3), (1, 1, 4), (9, 2, 3)], ids=lambda s: "x".join(map(str, s)))
+def test_interlaced_png_matches_reference_codec(shape, native, tmp_path):
+    ref = _ref_codec()
+    arr = _rand(*shape, 21)
+    path = str(tmp_path / "adam7.png")
+    with open(path, "wb") as f:
+        f.write(_adam7_png(arr))
+    want = ref.load_rgba(path)
+    assert (want[..., :shape[2]] == arr).all()
+    got = native.load_image(path)
+    assert got.shape == want.shape and (got == want).all()
