@@ -1,6 +1,6 @@
 // image_io.cpp — RGBA8 image files for LfLoader / storeResults, on zlib (the reference vendors stb_image v2.27 and
-// stb_image_write v1.16 for this: reference src/lfLoader.cpp:33-42, src/interpolator.cu:313).  Reads PNG (also Adam7-interlaced)
-// (grey, grey+alpha, RGB, RGBA, palette; 1–16 bit) and binary PPM/PGM; writes 8-bit RGBA/RGB PNG and PPM.
+// stb_image_write v1.16 for this: reference src/lfLoader.cpp:33-42, src/interpolator.cu:313).  Reads PNG (also Adam7-interlaced;
+// grey, grey+alpha, RGB, RGBA, palette; 1–16 bit), JPEG (jpeg.cpp) and binary PPM/PGM; writes 8-bit RGBA/RGB PNG and PPM.
 #include "image_io.h"
 
 #include <zlib.h>
@@ -284,6 +284,8 @@ void chunk(std::vector<uint8_t> &out, const char *type, const std::vector<uint8_
 
 } // namespace
 
+Image decodeJpeg(const std::vector<uint8_t> &file, const std::string &path); // jpeg.cpp
+
 Image loadImage(const std::string &path)
 {
     const std::vector<uint8_t> file = readFile(path);
@@ -291,7 +293,9 @@ Image loadImage(const std::string &path)
         return decodePng(file, path);
     if(file.size() >= 2 && file[0] == 'P' && (file[1] == '6' || file[1] == '5'))
         return decodePnm(file, path);
-    throw std::runtime_error("Cannot load image " + path + " (only PNG and binary PPM/PGM are supported)");
+    if(file.size() >= 2 && file[0] == 0xff && file[1] == 0xd8)
+        return decodeJpeg(file, path);
+    throw std::runtime_error("Cannot load image " + path + " (only PNG, JPEG and binary PPM/PGM are supported)");
 }
 
 void writePng(const std::string &path, int width, int height, int channels, const uint8_t *data, size_t strideBytes)

@@ -178,3 +178,104 @@ def test_interlaced_png_matches_reference_codec(shape, native, tmp_path):
     assert (want[..., :shape[2]] == arr).all()
     got = native.load_image(path)
     assert got.shape == want.shape and (got == want).all()
+
+
+def _photo(h, w, seed):
+    """Smooth content with edges and noise: exercises every AC band, both signs, chroma detail."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    r = 128 + 100 * np.sin(x / 7.0) * np.cos(y / 11.0) + 20 * rng.standard_normal((h, w))
+    g = 128 + 90 * np.sin((x + y) / 13.0) + (((x // 16 + y // 16) % 2) * 60 - 30)
+    b = 255 * ((x * 3 + y * 5) % 97) / 97.0
+    return np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("size", [(64, 96), (67, 101), (8, 8), (1, 1), (17, 3), (250, 333)], ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("kind", ["444", "422", "420", "grey", "420_restart", "444_progressive", "420_progressive", "q30_420", "q100_444"])
+def test_jpeg_decode_matches_reference_codec(kind, size, native, tmp_path):
+    """JPEG input (csrc/host/jpeg.cpp) against stb_image as the reference builds it: bit-exact RGBA."""
+    ref = _ref_codec()
+    h, w = size
+    arr = _photo(h, w, 7 + h)
+    img = Image.fromarray(arr, "RGB")
+    opts = {"quality": 85}
+    if kind == "grey":
+        img = img.convert("L")
+    if "444" in kind:
+        opts["subsampling"] = 0
+    if "422" in kind:
+        opts["subsampling"] = 1
+    if "420" in kind:
+        opts["subsampling"] = 2
+    if "restart" in kind:
+        opts["restart_marker_blocks"] = 3
+    if "progressive" in kind:
+        opts["progressive"] = True
+    if kind.startswith("q30"):
+        opts["quality"] = 30
+    if kind.startswith("q100"):
+        opts["quality"] = 100
+    path = str(tmp_path / f"{kind}.jpg")
+    img.save(path, "JPEG", **opts)
+    want = ref.load_rgba(path)
+    got = native.load_image(path)
+    assert got.shape == want.shape
+    assert (got == want).all(), (int((got != want).sum()), int(np.abs(got.astype(int) - want.astype(int)).max()))
+
+
+def test_jpeg_colour_models_match_reference_codec(native, tmp_path):
+    """Adobe-marked files: CMYK (four components), RGB kept as RGB (no YCbCr transform)."""
+    ref = _ref_codec()
+    arr = _photo(40, 56, 3)
+    cases = {"cmyk": (Image.fromarray(arr, "RGB").convert("CMYK"), {"quality": 90})}
+    try:
+        probe = str(tmp_path / "probe.jpg")
+        Image.fromarray(arr, "RGB").save(probe, "JPEG", keep_rgb=True)
+        cases["rgb_kept"] = (Image.fromarray(arr, "RGB"), {"quality": 90, "keep_rgb": True})
+    except (TypeError, OSError, ValueError):
+        pass
+    for name, (img, opts) in cases.items():
+        path = str(tmp_path / f"{name}.jpg")
+        img.save(path, "JPEG", **opts)
+        want = ref.load_rgba(path)
+        got = native.load_image(path)
+        assert got.shape == want.shape and (got == want).all(), name
+
+
+def test_jpeg_truncated_and_corrupt_files_do_not_crash(native, tmp_path):
+    arr = _photo(48, 64, 5)
+    good = str(tmp_path / "good.jpg")
+    Image.fromarray(arr, "RGB").save(good, "JPEG", quality=80, subsampling=2, progressive=True)
+    data = open(good, "rb").read()
+    rng = np.random.default_rng(0)
+    for i, cut in enumerate([3, 20, 100, len(data) // 3, len(data) // 2, len(data) - 2]):
+        p = str(tmp_path / f"cut{i}.jpg")
+        open(p, "wb").write(data[:cut])
+        try:
+            img = native.load_image(p)
+            assert img.shape == (48, 64, 4)      # a truncated scan still yields an image, like the reference's decoder
+        except RuntimeError as e:
+            assert "Cannot load image" in str(e)
+    for i in range(8):                           # random byte damage after the headers
+        b = bytearray(data)
+        for k in rng.integers(len(data) // 4, len(data), 6):
+            b[k] = int(rng.integers(0, 256))
+        p = str(tmp_path / f"bad{i}.jpg")
+        open(p, "wb").write(bytes(b))
+        try:
+            native.load_image(p)
+        except RuntimeError as e:
+            assert "Cannot load image" in str(e)
+
+
+def test_loader_reads_a_jpeg_grid(native, tmp_path):
+    """LfLoader on a directory of column_row.jpg files (reference naming, src/lfLoader.cpp:22-31)."""
+    ref = _ref_codec()
+    for col in range(2):
+        for row in range(3):
+            Image.fromarray(_photo(24, 40, 10 * col + row), "RGB").save(str(tmp_path / f"{row}_{col}.jpg"), "JPEG", quality=92)
+    cols, rows, lf = native.load_grid(str(tmp_path))
+    assert (cols, rows) == (2, 3) and lf.shape == (6, 24, 40, 4)
+    for col in range(2):
+        for row in range(3):
+            assert (lf[col * rows + row] == ref.load_rgba(str(tmp_path / f"{row}_{col}.jpg"))).all()
