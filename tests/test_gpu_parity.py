@@ -419,3 +419,47 @@ def test_focus_map_realistic_geometry(radius, gpu, oracle_c):
         assert (ctx.download_map(1) == oracle_c.focus_filter(want0, hp.block_radius)).all(), variant
     ctx.close()
 
+
+
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        cols, rows = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        if cols * rows < 2:
+            cols = 2
+        W = int(rng.choice([1, 2, 3, 5, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 160, 257, 300]))
+        H = int(rng.integers(1, 12))
+        V = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 70]))
+        focus = float(rng.choice([0.0, 0.05, 0.23, 0.6, -0.3]))
+        traj = rng.choice(["0,0,1,1", "0.071,0.071,0.93,0.93", "1,0,0,1", "0.5,0.5,0.5,0.5"])
+        cases.append((f"r{i}_{cols}x{rows}_{W}x{H}_v{V}", cols, rows, W, H, V, str(traj), focus))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_cases(16, 2025), ids=lambda c: c[0])
+def test_random_shapes_default_kernels(case, gpu, oracle_c):
+    """Ragged widths around the 32- and 128-pixel tile edges, one-row images, image counts that are not multiples of 16, view
+    counts around the 32- and 64-view pass edges, and a view sub-range: the default kernels (blend_wave / blend_persist behind
+    `auto`) against the oracle — STD bit-exact, TEN_WM within one LSB of the fp16-accumulate model."""
+    name, cols, rows, W, H, V, traj, focus = case
+    hp = gpu.build_params(cols, rows, W, H, traj, focus, 0.0, 3.0, 1.783, V)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, 77)
+    ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    want_std = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)
+    want_ten = oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, model=oracle_c.TEN_M16)
+    ctx.render("STD")
+    ctx.sync()
+    assert (ctx.download_views() == want_std).all()
+    ctx.render("TEN_WM")
+    ctx.sync()
+    assert np.abs(ctx.download_views().astype(int) - want_ten.astype(int)).max() <= TEN_TOL_LSB
+    if V >= 3:      # a view sub-range leaves the other views untouched
+        before = ctx.download_views()
+        v0, v1 = 1, V - 1
+        ctx.render("STD", v0=v0, v1=v1)
+        ctx.sync()
+        after = ctx.download_views()
+        assert (after[v0:v1] == want_std[v0:v1]).all()
+        assert (after[:v0] == before[:v0]).all() and (after[v1:] == before[v1:]).all()
+    ctx.close()
