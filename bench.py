@@ -33,6 +33,7 @@ VIEWS_PER_GPU = 64
 TRAJECTORY, FOCUS, ASPECT, EFFECT = "0.0,0.0,1.0,1.0", 0.23, 1.783, 3.0   # reference README.md:7
 SEED = 0x1F1F
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (= fp32 vector) peak: 256 CUs x 4 SIMDs x 64 flop/cycle x 2.4 GHz
 
 
 def cpu_baseline(hp, threads: int) -> dict:
@@ -187,6 +188,7 @@ def main() -> int:
                 traffic = json.load(open(tpath)).get(f"{args.method}/{args.variant}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        f_alg = 6.0 * n_images * VIEWS_PER_GPU * WIDTH * out_rows_n   # 3 channels × (multiply + add)
         line = {
             "metric": "novel views/sec + Gpix/sec, 8x8 LF @1080p TEN_WM" if args.method == "TEN_WM"
                       else "novel views/sec + Gpix/sec, 8x8 LF @1080p STD",
@@ -208,8 +210,15 @@ def main() -> int:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "frac_of_measured_copy_6290": achieved / 6290.0,
-                         "mfma_frac_of_2500_tflops": 6.0 * n_images * VIEWS_PER_GPU * WIDTH * out_rows_n / t_launch / 2.5e15},
+                         "mfma_frac_of_2500_tflops": f_alg / t_launch / 2.5e15},
         }
+        if args.method == "STD":
+            # the exact-fp32 path is bound by the fp32 matrix pipe: F_alg = 6·N·V·W·H flops per launch against
+            # the dense fp32 matrix peak (157.3 TFLOP/s: 256 CUs × 4 SIMDs × 64 flop/cycle × 2.4 GHz)
+            tflops = f_alg / t_launch / 1e12
+            line["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": tflops / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+                                "algorithmic_flops_per_launch": f_alg, "hbm_frac_of_8000_gbs": achieved / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(hp, threads)
