@@ -119,6 +119,7 @@ def main() -> int:
             ctx.sync()
         L.broadcast_grid(grid, src=0)    # the one collective of the job: 531 MB over xGMI (RCCL), outside the timed region
         torch.cuda.synchronize()
+        ctx.grid_modified()              # the attached planes were written by the collective, not through the ABI
         # host parameters for the whole trajectory; each rank keeps its own rows of the weight matrix
         total_views = VIEWS_PER_GPU * world
         hp, v0, v1 = L.rank_params(COLS, ROWS, WIDTH, HEIGHT, TRAJECTORY, FOCUS, 0.0, EFFECT, ASPECT, total_views, world, rank)

@@ -125,6 +125,13 @@ int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes);
 int lfi_broadcast_grid(lfi_ctx *const *ctxs, int n, int root);
 /* device pointer / size of the input planes currently in use */
 int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes);
+/* Tell the library that the contents of the input planes changed behind its back (a write through lfi_grid_device_ptr, or into
+ * a buffer given to lfi_attach_grid — e.g. the RCCL broadcast bench.py does after attaching).  The renders keep a derived copy
+ * of the inputs (planar, alpha dropped: 25 % fewer bytes to read per launch — DESIGN.md §4.1) which uploads through this API
+ * invalidate by themselves.  A context whose planes are attached or whose pointer has been handed out reads the RGBA planes
+ * directly on every launch, as the reference reads its surfaces, until this call has been made once: from then on the caller is
+ * trusted to repeat it after every such write.  No counterpart in the reference (its inputs are immutable after loadGPUData). */
+int lfi_grid_modified(lfi_ctx *ctx);
 /* fill the input planes on the device with the synthetic light field of SURVEY.md §8(d):
  * byte = hash32(seed, g, y, x, c) >> 24, alpha 255 (identical to oracle lfo_fill_synthetic) */
 int lfi_fill_synthetic(lfi_ctx *ctx, uint32_t seed);

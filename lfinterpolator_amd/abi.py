@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
     "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
+    "lfi_grid_modified",
 ]
 
 
@@ -89,6 +90,7 @@ def load_hip_library() -> C.CDLL:
         "lfi_download_quilt": (i, [vp, i, i, i, vp, sz]),
         "lfi_alloc_pinned": (i, [sz, C.POINTER(vp)]),
         "lfi_free_pinned": (i, [vp]),
+        "lfi_grid_modified": (i, [vp]),
         "lfi_upload_map": (i, [vp, i, vp, sz]),
         "lfi_set_stream": (i, [vp, vp]),
         "lfi_set_variant": (i, [vp, i, C.c_char_p]),
@@ -191,6 +193,10 @@ class Context:
         p, n = C.c_void_p(), C.c_size_t()
         self._check(self._lib.lfi_grid_device_ptr(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def grid_modified(self) -> None:
+        """The input planes were written behind the library's back (attached buffer, raw device pointer)."""
+        self._check(self._lib.lfi_grid_modified(self._h))
 
     def fill_synthetic(self, seed: int) -> None:
         self._check(self._lib.lfi_fill_synthetic(self._h, seed))

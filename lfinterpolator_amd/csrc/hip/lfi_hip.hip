@@ -19,6 +19,7 @@
 #include "blend_ten.hpp"
 #include "blend_ten_lds.hpp"
 #include "blend_ten_persist.hpp"
+#include "blend_planar.hpp"
 #include "blend_wave.hpp"
 #include "focus_factored.hpp"
 #include "lfi_device.hpp"
@@ -36,6 +37,7 @@ struct Variant
     bool packed_epilogue; // TEN_WM: needs weights in [0,2) (×2^15 copy)
     bool prequant = false; // can dump pre-quantisation accumulators (the generic kernels only)
     bool row_window = false; // honours a row window (the persistent kernels)
+    bool planar = false;     // reads the planar copy of the inputs when the launch qualifies (else its launcher falls back)
 };
 extern const Variant kTenVariants[];
 extern const Variant kStdVariants[];
@@ -80,6 +82,12 @@ struct lfi_ctx
     uint32_t flags = 0;
     float *prequant = nullptr;
     std::vector<lfi_float2> h_focus_offsets; // offsets of the focus_map_ids images (host copy: sizes the padded planes)
+    // planar copy of the inputs for blend_planar (built on demand; valid while planar_version == grid_version)
+    uint8_t *planar = nullptr;
+    size_t planar_bytes = 0;
+    int planar_pitch = 0, planar_padx = 0;
+    uint64_t grid_version = 1, planar_version = 0;
+    bool grid_tracked = true; // every write to the planes goes through this library (or is announced by lfi_grid_modified)
     void *focus_ws = nullptr; // workspace of the factored focus-map estimate (plan, E, K), allocated on first use
     size_t focus_ws_bytes = 0;
     int ten_variant = 0, std_variant = 0, focus_variant = 0;
@@ -154,6 +162,9 @@ KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
     a.v0 = v0;
     a.v1 = v1;
     a.n_focus_ids = c->n_focus_ids;
+    a.planar = nullptr; // set by launch_blend when the copy is valid for this launch
+    a.planar_pitch = c->planar_pitch;
+    a.planar_padx = c->planar_padx;
     a.fo_min_x = c->fo_min[0];
     a.fo_max_x = c->fo_max[0];
     a.fo_min_y = c->fo_min[1];
@@ -237,6 +248,22 @@ void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
         hipLaunchKernelGGL((lfi::blend_persist<STD, MT, false, NT_STORE, KC, WGS>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
 }
 
+// TEN_WM from the planar copy of the inputs (blend_planar.hpp) when launch_blend has validated it for this launch
+// (a.planar != nullptr: whole image, fixed focus, one K-chunk, one view pass), else blend_persist
+template <bool NT_STORE>
+void launch_planar(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    if(!a.planar || all_focus || a.k_pad > 64 || a.v1 - a.v0 > 64)
+    {
+        launch_persist<false, 2, NT_STORE>(c, a, all_focus);
+        return;
+    }
+    const int tiles_x = (a.width + 127) / 128;
+    const int n_tiles = tiles_x * a.out_rows;
+    const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    hipLaunchKernelGGL((lfi::blend_planar<2, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles);
+}
+
 // wave-private pipelines (blend_wave.hpp) where they apply — fixed focus, one K-chunk, one view pass — else blend_persist
 template <bool STD, int MT, bool NT_STORE>
 void launch_wave(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
@@ -277,6 +304,7 @@ void launch_std_valu(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 
 // first entry = default ("auto")
 const Variant kTenVariants[] = {
+    {"planar_m2_nt", launch_planar<true>, true, false, true, true}, // blend_persist where blend_planar does not apply
     {"persist_m2_nt", launch_persist<false, 2, true>, true, false, true},
     {"persist_m2", launch_persist<false, 2, false>, true, false, true},
     {"wave_m2_nt", launch_wave<false, 2, true>, true, false, true},
@@ -333,8 +361,58 @@ uint32_t flags_of(const lfi_ctx *c) { return c->flags; }
 dim3 pixel_grid_of(const lfi_ctx *c) { return pixel_grid(c); }
 int cu_count_of(const lfi_ctx *c) { return c->cu_count; }
 
-int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
+// Make the planar copy of the inputs valid for a fixed-focus launch with the current parameters; returns false (and leaves the
+// launch on the RGBA planes) when the copy may not be used: row window, inputs the library cannot track, absurd offsets.
+bool ensure_planar(lfi_ctx *c)
 {
+    if(c->windowed || !c->grid_tracked)
+        return false;
+    const int reach = std::max(std::max(std::abs(c->fo_min[0]), std::abs(c->fo_max[0])), 0);
+    if(reach > 4 * c->width + 4096)
+        return false;
+    // a tile's 128-byte run may start `reach` pixels left of column 0 and, for the ragged last tile of a row, end 127 pixels past
+    // the row plus `reach`: pad by reach + 128 on both sides
+    const int need = (reach + 128 + 3) / 4 * 4;
+    if(c->planar && c->planar_version == c->grid_version && c->planar_padx >= need)
+        return true;
+    const int padx = std::max(need, c->planar_padx);
+    const int pitch = (c->width + 2 * padx + 15) / 16 * 16;
+    const size_t bytes = (size_t)c->n * 12 * c->height * pitch;
+    if(bytes != c->planar_bytes)
+    {
+        if(c->planar)
+            (void)hipFree(c->planar);
+        c->planar = nullptr;
+        c->planar_bytes = 0;
+        c->planar_version = 0;
+        if(hipMalloc(reinterpret_cast<void **>(&c->planar), bytes) != hipSuccess)
+        {
+            (void)hipGetLastError(); // not enough memory for the copy: render from the RGBA planes
+            c->planar = nullptr;
+            return false;
+        }
+        c->planar_bytes = bytes;
+    }
+    c->planar_padx = padx;
+    c->planar_pitch = pitch;
+    hipLaunchKernelGGL(lfi::planar_build, dim3((pitch / 4 + 255) / 256, c->height, c->n), dim3(256), 0, c->stream, c->grid, c->planar,
+                       c->width, c->height, pitch, padx);
+    if(hipGetLastError() != hipSuccess)
+        return false;
+    c->planar_version = c->grid_version;
+    return true;
+}
+
+int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
+{
+    KernelArgs a = a_in;
+    if(method == LFI_METHOD_TEN_WM && !all_focus && !a.prequant && kTenVariants[c->ten_variant].planar && c->weights_scalable &&
+       !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) && a.k_pad <= 64 && a.v1 - a.v0 <= 64 && ensure_planar(c))
+    {
+        a.planar = c->planar;
+        a.planar_pitch = c->planar_pitch;
+        a.planar_padx = c->planar_padx;
+    }
     if(c->windowed)
     {
         // a row window is honoured by the persistent fixed-focus kernels only
@@ -402,6 +480,11 @@ void free_grid(lfi_ctx *c)
         (void)hipFree(c->focus_ws);
     c->focus_ws = nullptr;
     c->focus_ws_bytes = 0;
+    if(c->planar)
+        (void)hipFree(c->planar);
+    c->planar = nullptr;
+    c->planar_bytes = 0;
+    c->planar_version = 0;
 }
 
 // the factored estimate (focus_factored.hpp): carve the workspace, then plan → pad → E → exact keys → pick.
@@ -692,6 +775,8 @@ int lfi_set_grid(lfi_ctx *ctx, int cols, int rows, int width, int height)
     ctx->grid_bytes = plane_bytes(ctx) * ctx->n;
     LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->grid), ctx->grid_bytes));
     ctx->own_grid = true;
+    ctx->grid_version++;
+    ctx->grid_tracked = true;
     LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->maps), plane_bytes(ctx) * 2));
     LFI_HIP(ctx, hipMemsetAsync(ctx->maps, 0, plane_bytes(ctx) * 2, ctx->stream));
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -740,6 +825,7 @@ int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_byte
     LFI_HIP(ctx, hipMemcpy2DAsync(ctx->grid + in_plane_bytes(ctx) * g, (size_t)ctx->width * 4, rgba + (size_t)ctx->in_y0 * pitch_bytes,
                                   pitch_bytes, (size_t)ctx->width * 4, ctx->in_rows, hipMemcpyHostToDevice, ctx->stream));
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->grid_version++;
     return LFI_OK;
 }
 
@@ -761,6 +847,8 @@ int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes)
     ctx->grid = static_cast<uint8_t *>(device_ptr);
     ctx->own_grid = false;
     ctx->grid_bytes = bytes;
+    ctx->grid_version++;
+    ctx->grid_tracked = false; // the caller writes this buffer itself: see lfi_grid_modified
     return LFI_OK;
 }
 
@@ -817,7 +905,10 @@ int lfi_broadcast_grid(lfi_ctx *const *ctxs, int n, int root)
             status = fail(r0, LFI_EHIP, "hipStreamSynchronize after the broadcast failed");
     }
     for(int i = 0; i < n; i++)
+    {
         (void)nc.CommDestroy(comms[i]);
+        ctxs[i]->grid_version++;
+    }
     return status;
 }
 
@@ -828,6 +919,19 @@ int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes)
     *out_ptr = ctx->grid;
     if(out_bytes)
         *out_bytes = ctx->grid ? in_plane_bytes(ctx) * ctx->n : 0;
+    ctx->grid_tracked = false; // the caller may write through the pointer: see lfi_grid_modified
+    ctx->grid_version++;
+    return LFI_OK;
+}
+
+int lfi_grid_modified(lfi_ctx *ctx)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->grid)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    ctx->grid_version++;
+    ctx->grid_tracked = true; // the caller announces its writes from now on
     return LFI_OK;
 }
 
@@ -839,6 +943,7 @@ int lfi_fill_synthetic(lfi_ctx *ctx, uint32_t seed)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
     if(int rc = bind(ctx))
         return rc;
+    ctx->grid_version++;
     hipLaunchKernelGGL(lfi::fill_synthetic, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, ctx->n, ctx->width,
                        ctx->in_rows, ctx->in_y0, seed);
     LFI_HIP(ctx, hipGetLastError());

@@ -140,3 +140,57 @@ def test_pinned_host_buffers(gpu, oracle_c):
     assert (want == oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)).all()
     ctx.close()
 
+
+
+def test_input_changes_reach_the_renders(gpu, oracle_c):
+    """TEN_WM renders read a derived (planar) copy of the inputs: every way of changing the inputs must reach them.
+    Uploads through the ABI invalidate the copy; an attached buffer is read directly until lfi_grid_modified has been called,
+    and after that call the caller's announcements are honoured."""
+    torch = pytest.importorskip("torch")
+    cols, rows, W, H = 4, 4, 160, 12
+    hp = gpu.build_params(cols, rows, W, H, "0.1,0.2,0.8,0.9", 0.2, 0.0, 2.0, 1.5, 8)
+    lf_a = oracle_c.synthetic_lf(cols * rows, W, H, 1)
+    lf_b = oracle_c.synthetic_lf(cols * rows, W, H, 2)
+
+    def want(lf):
+        return oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, model=oracle_c.TEN_M16)
+
+    def close(out, lf):
+        return np.abs(out.astype(int) - want(lf).astype(int)).max() <= 1
+
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.upload_grid(lf_a)
+    ctx.set_params(hp)
+    ctx.render("TEN_WM"); ctx.sync()
+    assert close(ctx.download_views(), lf_a)
+    ctx.upload_image(3, lf_b[3])                       # one image replaced through the ABI
+    mixed = lf_a.copy(); mixed[3] = lf_b[3]
+    ctx.render("TEN_WM"); ctx.sync()
+    assert close(ctx.download_views(), mixed)
+    ctx.fill_synthetic(0x77)                           # all of them regenerated on the device
+    ctx.render("TEN_WM"); ctx.sync()
+    assert close(ctx.download_views(), oracle_c.synthetic_lf(cols * rows, W, H, 0x77))
+    # caller-owned planes: no announcement yet → every launch reads them as they are
+    t = torch.from_numpy(lf_a).cuda()
+    ctx.attach_grid(t.data_ptr(), t.numel())
+    ctx.render("TEN_WM"); ctx.sync()
+    assert close(ctx.download_views(), lf_a)
+    t.copy_(torch.from_numpy(lf_b)); torch.cuda.synchronize()
+    ctx.render("TEN_WM"); ctx.sync()
+    assert close(ctx.download_views(), lf_b)
+    # from the first announcement on, the copy is used and refreshed on every further announcement
+    ctx.grid_modified()
+    ctx.render("TEN_WM"); ctx.sync()
+    assert close(ctx.download_views(), lf_b)
+    t.copy_(torch.from_numpy(lf_a)); torch.cuda.synchronize()
+    ctx.grid_modified()
+    ctx.render("TEN_WM"); ctx.sync()
+    assert close(ctx.download_views(), lf_a)
+    # a new parameter set with larger offsets rebuilds the copy with more padding
+    hp2 = gpu.build_params(cols, rows, W, H, "0.1,0.2,0.8,0.9", 0.9, 0.0, 2.0, 1.5, 8)
+    ctx.set_params(hp2)
+    ctx.render("TEN_WM"); ctx.sync()
+    w2 = oracle_c.blend_ten(lf_a, hp2.focused_offsets, hp2.offsets, hp2.weights, model=oracle_c.TEN_M16)
+    assert np.abs(ctx.download_views().astype(int) - w2.astype(int)).max() <= 1
+    ctx.close()

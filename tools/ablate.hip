@@ -80,6 +80,42 @@ __global__ void __launch_bounds__(256) k_pattern(const uint32_t *__restrict__ gr
     }
 }
 
+// PLANAR read probe: the inputs as 3 x 64 byte planes (one per image and colour channel, no alpha): a wave = a run of 256 pixels
+// of one row, a lane reads one dword (4 pixels of one channel) per (image, channel) = 192 loads of 256 B per wave instead of
+// 64 loads of 1 KB; writes as k_pattern<4> (64 planes, 16 B per lane).  Would dropping the alpha bytes from the read side pay?
+template <bool WRITE, bool NT, int UNROLL>
+__global__ void __launch_bounds__(256) k_planar(const uint32_t *__restrict__ planes, uint32_t *__restrict__ views, const Offs offs, int tiles_x, int n_tiles)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t b = xcd_contig(blockIdx.x, gridDim.x);
+    const int tile = b * 4 + wave;
+    if(tile >= n_tiles) return;
+    const int y = tile / tiles_x, x0 = (tile - y * tiles_x) * 256;
+    uint32_t acc[4] = {lane * 0x01010101u, 1u, 2u, 3u};
+    const size_t plane_dw = PLANE / 4; // dwords per byte plane
+#pragma unroll UNROLL
+    for(int g = 0; g < NIMG; g++)
+    {
+        const int sy = min(max(y + offs.oy[g], 0), H - 1);
+        int sx = x0 + 4 * lane + (offs.ox[g] & ~3); // dword-aligned (the real thing would pick one of four byte-shifted copies)
+        sx = min(max(sx, 0), W - 4);
+#pragma unroll
+        for(int c = 0; c < 3; c++)
+            acc[c] ^= planes[(size_t)(3 * g + c) * plane_dw + ((size_t)sy * W + sx) / 4];
+    }
+    if(WRITE)
+    {
+#pragma unroll UNROLL
+        for(int v = 0; v < NV; v++)
+        {
+            uint32_t *p = views + (size_t)v * PLANE + (size_t)y * W + x0 + 4 * lane;
+            u32x4 t = {acc[0] + v, acc[1], acc[2], acc[3]};
+            if(NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(p)); else *reinterpret_cast<u32x4 *>(p) = t;
+        }
+    }
+    else if((acc[0] ^ acc[1] ^ acc[2]) == 0x12345678u) views[tile] = acc[0];
+}
+
 template <typename F> float time_it(F f, int runs = 10);
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -161,6 +197,16 @@ void run(const char *name, const uint32_t *grid, uint32_t *views, const Offs &o)
     printf("%-44s %8.1f us  %7.0f GB/s\n", name, ms * 1e3, bytes / ms / 1e6);
 }
 
+template <bool WRITE, bool NT, int UNROLL>
+void run_planar(const char *name, const uint32_t *planes, uint32_t *views, const Offs &o)
+{
+    const int tiles_x = W / 256, n_tiles = tiles_x * H;
+    const int blocks = (n_tiles + 3) / 4;
+    float ms = time_it([&] { hipLaunchKernelGGL((k_planar<WRITE, NT, UNROLL>), dim3(blocks), dim3(256), 0, 0, planes, views, o, tiles_x, n_tiles); });
+    const double moved = 1.0 * W * H * (3 * NIMG + (WRITE ? 4 * NV : 0));
+    printf("%-44s %8.1f us  %7.0f GB/s moved (%.0f MB)\n", name, ms * 1e3, moved / ms / 1e6, moved / 1e6);
+}
+
 int main()
 {
     uint32_t *grid, *views;
@@ -192,6 +238,10 @@ int main()
     run<4, true, true, true, true, 16>("gather+scatter x4 xcd nt u16", grid, views, o);
     run<4, true, true, false, false, 16>("gather+scatter x4 noxcd u16", grid, views, o);
     run<4, true, true, false, true, 16>("gather+scatter x4 noxcd nt u16", grid, views, o);
+    run_planar<false, false, 16>("planar gather only (3 B/px) u16", grid, views, o);
+    run_planar<true, true, 16>("planar gather (3 B/px) + scatter x4 nt u16", grid, views, o);
+    run_planar<true, true, 8>("planar gather (3 B/px) + scatter x4 nt u8", grid, views, o);
+    run<4, true, true, true, true, 16>("gather+scatter x4 xcd nt u16 (again)", grid, views, o);
     run_dma<true, false, false, 32>("dma gather x4 unaligned 32KB/WG", grid, views, o);
     run_dma<true, true, false, 32>("dma gather x4 aligned16 32KB/WG", grid, views, o);
     run_dma<false, false, false, 32>("dma gather dword 32KB/WG", grid, views, o);
