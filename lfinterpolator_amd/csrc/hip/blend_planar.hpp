@@ -12,8 +12,7 @@
 //
 // planar_build — once per change of the inputs (the context tracks them, include/lfi.h lfi_grid_modified): 12 byte planes per
 //                image from its RGBA plane.
-// blend_planar — the workgroup pipeline of blend_persist (one K-chunk ≤ 64 images, one view pass ≤ 64 views, fixed focus, whole
-//                image; weights loaded once) with 24 LDS-DMA pieces of 8 runs × 128 bytes per 128-pixel tile, 6 per wave (a run
+// blend_planar — the workgroup pipeline of blend_persist (fixed focus, whole image; any number of images and views) with 24 LDS-DMA pieces of 8 runs × 128 bytes per 128-pixel tile, 6 per wave (a run
 //                per wave-sized tile would be 32 bytes: four times the cache-line requests per byte — measured slower than
 //                the RGBA kernel); LDS bytes [channel][image][128 pixels]; the MFMA B operand is assembled from byte reads
 //                (a pixel byte IS the fp16 subnormal's mantissa).
@@ -53,14 +52,17 @@ __global__ void __launch_bounds__(256) planar_build(const uint8_t *__restrict__ 
         }
 }
 
+// Units as in blend_persist: (tile, view pass, chunk of ≤ 64 images); the pixel bytes of a tile stay in LDS for every view
+// pass when the image stack fits one chunk; the weight fragments are fetched per unit — or once per workgroup when there is a
+// single chunk and a single pass (config 2, every bench step).
 template <int MT, bool NT_STORE>
-__global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const int tiles_x, const int n_tiles)
+__global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes)
 {
     constexpr int KC = 64, KS = KC / 16, VPP = MT * 32, TPX = 128;
     constexpr int W_DW = (KC / 8) * VPP * 4; // fp16 weight fragments [k-octet][view] × 16 B
-    constexpr int PX_B = 3 * KC * TPX;       // bytes of one pixel buffer: [channel][image][128 pixels] = 24 KB
-    constexpr int PIECES = PX_B / 1024;      // 24 LDS-DMA pieces per tile, 6 per wave
-    __shared__ __attribute__((aligned(16))) uint32_t lds[W_DW + 2 * (PX_B / 4)];
+    constexpr int PX_B = 3 * KC * TPX;       // bytes of one pixel buffer: [channel][image of the chunk][128 pixels] = 24 KB
+    constexpr int OFF_DW = 2 * LFI_MAX_IMAGES; // the integer offsets of every image (per-lane lookups by ds_read, not vector loads)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * (PX_B / 4) + 2 * W_DW + OFF_DW];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -68,75 +70,105 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
     const int W = a.width, H = a.height;
     const size_t oplane_px = (size_t)W * (size_t)a.out_rows;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr_t)lds)));
-    const uint32_t px_base = lds_base + W_DW * 4;
-    const int kc = a.k_pad; // ≤ KC (host)
-
-    // ---- once per workgroup: the weight fragments ------------------------------------------------------------------------------
-    for(int o = wave; 8 * o < kc; o += 4)
-        if(lane < VPP)
-            dma16(a.w16s + (size_t)(a.v0 + lane) * a.k_pad + 8 * o, lds_base + uint32_t(o) * (VPP * 16));
-
-    // ---- per lane, once: piece p = wave + 4 j (j = 0…5) moves the runs 8p … 8p+7 of the tile — run ρ = channel·64 + image, 128
-    // bytes = 128 pixels, eight lanes × 16 bytes — so this lane serves run 8p + (lane >> 3): its image's offsets and the byte
-    // offset of its (image, channel) plane group (shift 0)
-    constexpr int PPW = PIECES / 4;
-    int ox[PPW], oy[PPW];
-    size_t plane0[PPW];
-    bool live[PPW];
     const size_t shift_stride = (size_t)H * a.planar_pitch; // one byte plane
-#pragma unroll
-    for(int j = 0; j < PPW; j++)
+    int2 *off_table = reinterpret_cast<int2 *>(lds + 2 * (PX_B / 4) + 2 * W_DW);
+    for(int g = threadIdx.x; g < a.n_images; g += 256)
     {
-        const int run = 8 * (wave + 4 * j) + (lane >> 3), c = run / KC, gq = run % KC;
-        live[j] = gq < kc; // chunks shorter than 64 images: those runs are never read
-        const int g = min(gq, a.n_images - 1); // padded images (zero weights) re-read the last one
         const lfi_int2 o = a.focused[g];
-        ox[j] = o.x;
-        oy[j] = o.y;
-        plane0[j] = ((size_t)g * 3 + c) * 4 * shift_stride;
+        off_table[g] = make_int2(o.x, o.y);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier(); // weights in LDS
-    asm volatile("" ::: "memory");
+    const bool single_chunk = a.k_pad <= KC;
+    const bool static_weights = single_chunk && view_passes == 1;
 
-    auto issue = [&](const int t, const int buf) {
+    auto issue_weights = [&](const int pass, const int k0, const int wb) {
+        const int kc = min(KC, a.k_pad - k0);
+        const uint32_t w_addr = lds_base + 2 * PX_B + uint32_t(wb) * (W_DW * 4);
+        for(int o = wave; 8 * o < kc; o += 4)
+            if(lane < VPP)
+                dma16(a.w16s + (size_t)(a.v0 + pass * VPP + lane) * a.k_pad + k0 + 8 * o, w_addr + uint32_t(o) * (VPP * 16));
+    };
+    // pixel bytes of one unit: piece p (1 KB) = channel p / 8, images 8 (p % 8) … +7 of the chunk, 128 bytes = 128 pixels each (eight
+    // lanes × 16 bytes per image); wave w moves pieces w, w + 4, …  What a lane needs per piece — its image's integer offsets and
+    // the byte offset of that image's (channel, shift 0) plane — depends on the chunk only: looked up once per kernel when the
+    // stack is one chunk, once per unit otherwise.
+    struct Pieces
+    {
+        int ox[6], oy[6];
+        size_t plane0[6];
+    };
+    auto lookup = [&](const int k0) {
+        Pieces pc;
+#pragma unroll
+        for(int j = 0; j < 6; j++)
+        {
+            const int p = wave + 4 * j, c = p >> 3, octet = p & 7;
+            const int g = min(k0 + 8 * octet + (lane >> 3), a.n_images - 1); // padded images (zero weights) re-read the last one
+            const int2 o = off_table[g];
+            pc.ox[j] = o.x;
+            pc.oy[j] = o.y;
+            pc.plane0[j] = ((size_t)g * 3 + c) * 4 * shift_stride;
+        }
+        return pc;
+    };
+    auto issue_pixels = [&](const int t, const int k0, const int pb, const Pieces &pc) {
         const int ty = t / tiles_x;
         const int y = a.out_y0 + ty;
         const int x0 = (t - ty * tiles_x) * TPX;
-        const uint32_t dst = px_base + uint32_t(buf) * PX_B;
+        const int kc = min(KC, a.k_pad - k0);
+        const uint32_t dst = lds_base + uint32_t(pb) * PX_B;
 #pragma unroll
-        for(int j = 0; j < PPW; j++)
+        for(int j = 0; j < 6; j++)
         {
-            // the run of this lane's image starts at pixel x0 + ox: dword aligned in shift copy (x0 + ox + padx) & 3
-            const int sy = clampi(y + oy[j], 0, H - 1);
-            const int start = x0 + ox[j] + a.planar_padx; // ≥ 0: the padding exceeds every offset
+            const int p = wave + 4 * j;
+            if(8 * (p & 7) >= kc)
+                continue; // wave-uniform: the chunk is shorter (its length is a multiple of 16)
+            // the run starts at pixel x0 + ox: dword aligned in shift copy (x0 + ox + padx) & 3; the padding exceeds every offset
+            const int sy = clampi(y + pc.oy[j], 0, H - 1);
+            const int start = x0 + pc.ox[j] + a.planar_padx;
             const int k = start & 3;
-            const uint8_t *src = a.planar + plane0[j] + ((size_t)k * H + sy) * a.planar_pitch + (start - k) + 16 * (lane & 7);
-            // whole pieces are skipped only (kc is a multiple of 16, a piece is 8 images of one channel)
-            if(__builtin_amdgcn_ballot_w64(live[j]) != 0ull)
-                dma16(src, dst + uint32_t(wave + 4 * j) * 1024u);
+            dma16(a.planar + pc.plane0[j] + ((size_t)k * H + sy) * a.planar_pitch + (start - k) + 16 * (lane & 7), dst + uint32_t(p) * 1024u);
         }
     };
 
-    // ---- tiles j, j+G, … (as blend_persist): wait own pieces → barrier → issue next → compute → epilogue --------------------------
     const int G = gridDim.x;
     int t = int(xcd_contiguous(blockIdx.x, gridDim.x));
     if(t >= n_tiles)
         return;
-    int buf = 0;
+    __syncthreads(); // the offset table is complete
+    int pass = 0, k0 = 0, pbuf = 0, wbuf = 0;
     int prev_stores = 0;
-    issue(t, 0);
+    Pieces pieces = lookup(0);
+    issue_weights(0, 0, 0);
+    issue_pixels(t, 0, 0, pieces);
 
     f32x16 acc[MT][3];
-    f32x16 zero16;
 #pragma unroll
-    for(int e = 0; e < 16; e++)
-        zero16[e] = 0.0f;
-    const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(lds);
-    const uint8_t *px_bytes = reinterpret_cast<const uint8_t *>(lds + W_DW) + wave * 32 + r + 8 * h * TPX;
+    for(int m = 0; m < MT; m++)
+#pragma unroll
+        for(int c = 0; c < 3; c++)
+#pragma unroll
+            for(int e = 0; e < 16; e++)
+                acc[m][c][e] = 0.0f;
+
     while(true)
     {
-        const int nt = t + G;
+        // next unit (chunks innermost, then view passes, then tiles)
+        int nt = t, npass = pass, nk0 = k0 + KC;
+        if(nk0 >= a.k_pad)
+        {
+            nk0 = 0;
+            npass = pass + 1;
+            if(npass >= view_passes)
+            {
+                npass = 0;
+                nt = t + G;
+            }
+        }
+        const bool have_next = nt < n_tiles;
+        const bool next_needs_pixels = !single_chunk || nt != t;
+        const int npbuf = next_needs_pixels ? (pbuf ^ 1) : pbuf;
+        const int nwbuf = static_weights ? wbuf : (wbuf ^ 1);
+
         if(prev_stores >= 32)
             asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else if(prev_stores >= 24)
@@ -147,14 +179,25 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier(); // everybody's pieces have landed; everybody is done with the buffer about to be refilled
+        __builtin_amdgcn_s_barrier(); // everybody's pieces have landed; everybody is done with the buffers about to be refilled
         asm volatile("" ::: "memory");
-        if(nt < n_tiles)
-            issue(nt, buf ^ 1);
+        if(have_next)
+        {
+            if(!static_weights)
+                issue_weights(npass, nk0, nwbuf);
+            if(next_needs_pixels)
+            {
+                if(!single_chunk)
+                    pieces = lookup(nk0);
+                issue_pixels(nt, nk0, npbuf, pieces);
+            }
+        }
 
-        // ---- k-loop: as unit_ten (blend_core.hpp), the B operand assembled from bytes: image g of channel c at byte
+        // ---- k-loop: as unit_ten (blend_core.hpp), the B operand assembled from bytes: image g of the chunk, channel c, at byte
         // (c·64 + g)·128 + pixel of the buffer; this lane's pixel 32·wave + r, images 16 ks + 8 h + j
-        const uint8_t *col = px_bytes + buf * PX_B;
+        const int kc = min(KC, a.k_pad - k0);
+        const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(lds + 2 * (PX_B / 4) + wbuf * W_DW);
+        const uint8_t *col = reinterpret_cast<const uint8_t *>(lds) + pbuf * PX_B + wave * 32 + r + 8 * h * TPX;
 #pragma unroll
         for(int ks = 0; ks < KS; ks++)
         {
@@ -179,19 +222,24 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
                     const half8 bfrag = __builtin_bit_cast(half8, bc[c]);
 #pragma unroll
                     for(int m = 0; m < MT; m++)
-                        acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[m], bfrag, ks == 0 ? zero16 : acc[m][c], 0, 0, 0);
+                        acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[m], bfrag, acc[m][c], 0, 0, 0);
                 }
             }
         }
 
+        prev_stores = 0;
+        if(k0 + KC >= a.k_pad) // last chunk of the tile's pass: epilogue
         {
             const int ty = t / tiles_x;
-            prev_stores = store_tile<false, MT, NT_STORE, false>(a, acc, a.v0, ty, (t - ty * tiles_x) * TPX + wave * 32, r, h, oplane_px);
+            prev_stores = store_tile<false, MT, NT_STORE, true>(a, acc, a.v0 + pass * VPP, ty, (t - ty * tiles_x) * TPX + wave * 32, r, h, oplane_px);
         }
-        if(nt >= n_tiles)
+        if(!have_next)
             break;
         t = nt;
-        buf ^= 1;
+        pass = npass;
+        k0 = nk0;
+        pbuf = npbuf;
+        wbuf = nwbuf;
     }
 }
 

@@ -249,19 +249,20 @@ void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 }
 
 // TEN_WM from the planar copy of the inputs (blend_planar.hpp) when launch_blend has validated it for this launch
-// (a.planar != nullptr: whole image, fixed focus, one K-chunk, one view pass), else blend_persist
+// (a.planar != nullptr: whole image, fixed focus), else blend_persist
 template <bool NT_STORE>
 void launch_planar(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
-    if(!a.planar || all_focus || a.k_pad > 64 || a.v1 - a.v0 > 64)
+    if(!a.planar || all_focus)
     {
         launch_persist<false, 2, NT_STORE>(c, a, all_focus);
         return;
     }
     const int tiles_x = (a.width + 127) / 128;
     const int n_tiles = tiles_x * a.out_rows;
+    const int passes = (a.v1 - a.v0 + 63) / 64;
     const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
-    hipLaunchKernelGGL((lfi::blend_planar<2, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles);
+    hipLaunchKernelGGL((lfi::blend_planar<2, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
 }
 
 // wave-private pipelines (blend_wave.hpp) where they apply — fixed focus, one K-chunk, one view pass — else blend_persist
@@ -406,8 +407,10 @@ bool ensure_planar(lfi_ctx *c)
 int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
 {
     KernelArgs a = a_in;
+    // The planar copy pays where reads are a large share of the traffic: not for launches that write many more views than they
+    // read images (config 4 on one GPU, 256 views from 64 images: +6 % — the byte-wise operand assembly repeats per view pass).
     if(method == LFI_METHOD_TEN_WM && !all_focus && !a.prequant && kTenVariants[c->ten_variant].planar && c->weights_scalable &&
-       !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) && a.k_pad <= 64 && a.v1 - a.v0 <= 64 && ensure_planar(c))
+       !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) && a.v1 - a.v0 <= std::max(c->n, 64) && ensure_planar(c))
     {
         a.planar = c->planar;
         a.planar_pitch = c->planar_pitch;
