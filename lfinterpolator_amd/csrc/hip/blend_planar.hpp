@@ -7,15 +7,15 @@
 // copies shifted by 0…3 bytes: a run that starts at pixel x0 is then a dword-aligned run of copy (x0 + pad) mod 4.  The copies
 // are padded left and right by more than the largest offset with replicated edge pixels, so clamp-to-edge in x
 // (cudaBoundaryModeClamp, src/kernels.cu:125) needs no per-pixel path at all; in y the row index is clamped per image.
-// The memory system gives this pattern (192 streams of 32-byte runs per wave instead of 64 of 128 bytes) the full saving:
-// gather + scatter 164–167 µs instead of 183–185 µs at config 2 (tools/ablate.hip, "planar").
+// The memory system gives this pattern (192 byte-plane streams instead of 64 RGBA-plane streams) the full saving: gather +
+// scatter with no arithmetic 164–167 µs instead of 183–185 µs at config 2 (tools/ablate.hip, "planar").
 //
 // planar_build — once per change of the inputs (the context tracks them, include/lfi.h lfi_grid_modified): 12 byte planes per
 //                image from its RGBA plane.
-// blend_planar — the workgroup pipeline of blend_persist (fixed focus, whole image; any number of images and views) with 24 LDS-DMA pieces of 8 runs × 128 bytes per 128-pixel tile, 6 per wave (a run
-//                per wave-sized tile would be 32 bytes: four times the cache-line requests per byte — measured slower than
-//                the RGBA kernel); LDS bytes [channel][image][128 pixels]; the MFMA B operand is assembled from byte reads
-//                (a pixel byte IS the fp16 subnormal's mantissa).
+// blend_planar — the workgroup pipeline of blend_persist (fixed focus, whole image; any number of images and views): 24 LDS-DMA
+//                pieces of 8 runs × 128 bytes per unit, 6 per wave (a run per wave-sized tile would be 32 bytes: four times the
+//                cache-line requests per byte — measured slower than the RGBA kernel); LDS bytes [channel][image][128 pixels];
+//                the MFMA B operand is assembled from byte reads (a pixel byte IS the fp16 subnormal's mantissa).
 // Arithmetic, weights, operand maps and epilogue are those of blend_persist / blend_wave (blend_core.hpp): identical output bytes.
 // Replaces Kernels::Tensors::process<false> (reference src/kernels.cu:398-461).
 #pragma once
