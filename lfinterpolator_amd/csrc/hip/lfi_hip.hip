@@ -306,6 +306,7 @@ void launch_std_valu(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 // first entry = default ("auto")
 const Variant kTenVariants[] = {
     {"planar_m2_nt", launch_planar<true>, true, false, true, true}, // blend_persist where blend_planar does not apply
+    {"planar_m2", launch_planar<false>, true, false, true, true},
     {"persist_m2_nt", launch_persist<false, 2, true>, true, false, true},
     {"persist_m2", launch_persist<false, 2, false>, true, false, true},
     {"wave_m2_nt", launch_wave<false, 2, true>, true, false, true},
