@@ -71,6 +71,48 @@ __device__ __forceinline__ void unit_ten(const uint32_t *col, const u32x4 *w_buf
     }
 }
 
+// TEN_WM k-loop of one unit from PLANAR pixel bytes (blend_planar.hpp): LDS bytes [channel][image of the chunk][TPX pixels], col =
+// this lane's pixel at image 8h of channel 0.  A pixel byte is the mantissa of the fp16 subnormal b·2^-24, so the B operand of
+// an image pair is lo | hi << 16 of two byte reads.  Otherwise as unit_ten.
+template <int MT, int TPX, int KC, bool ZERO_FIRST>
+__device__ __forceinline__ void unit_ten_bytes(const uint8_t *col, const u32x4 *w_buf, const int r, const int h, const int kc,
+                                               f32x16 (&acc)[MT][3])
+{
+    constexpr int VPP = MT * 32, KS = KC / 16;
+    f32x16 zero16;
+#pragma unroll
+    for(int e = 0; e < 16; e++)
+        zero16[e] = 0.0f;
+#pragma unroll
+    for(int ks = 0; ks < KS; ks++)
+    {
+        if(16 * ks < kc)
+        {
+            half8 wfrag[MT];
+#pragma unroll
+            for(int m = 0; m < MT; m++)
+                wfrag[m] = __builtin_bit_cast(half8, w_buf[(2 * ks + h) * VPP + m * 32 + r]);
+            u32x4 bc[3];
+#pragma unroll
+            for(int c = 0; c < 3; c++)
+#pragma unroll
+                for(int q = 0; q < 4; q++)
+                {
+                    const uint32_t lo = col[(c * KC + 16 * ks + 2 * q) * TPX], hi = col[(c * KC + 16 * ks + 2 * q + 1) * TPX];
+                    bc[c][q] = lo | (hi << 16);
+                }
+#pragma unroll
+            for(int c = 0; c < 3; c++)
+            {
+                const half8 bfrag = __builtin_bit_cast(half8, bc[c]);
+#pragma unroll
+                for(int m = 0; m < MT; m++)
+                    acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[m], bfrag, (ZERO_FIRST && ks == 0) ? zero16 : acc[m][c], 0, 0, 0);
+            }
+        }
+    }
+}
+
 // STD k-loop of one unit, exact fp32: MFMA q of a k-step multiplies image pair (16ks+2q, 16ks+2q+1): k = 0 ↔ lower half-wave,
 // k = 1 ↔ upper, accumulated in that order = the reference's ascending-g fmaf chain (src/kernels.cu:328-338).
 // col = this lane's pixel column at image h.  Weights, W32 = false: the fp16 fragments of the TEN_WM layout, this lane's view

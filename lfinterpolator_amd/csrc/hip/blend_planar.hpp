@@ -56,13 +56,18 @@ __global__ void __launch_bounds__(256) planar_build(const uint8_t *__restrict__ 
 // pass when the image stack fits one chunk; the weight fragments are fetched per unit — or once per workgroup when there is a
 // single chunk and a single pass (config 2, every bench step).
 template <int MT, bool NT_STORE>
-__global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes)
+__global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes, const int ring3)
 {
-    constexpr int KC = 64, KS = KC / 16, VPP = MT * 32, TPX = 128;
+    constexpr int KC = 64, VPP = MT * 32, TPX = 128;
     constexpr int W_DW = (KC / 8) * VPP * 4; // fp16 weight fragments [k-octet][view] × 16 B
     constexpr int PX_B = 3 * KC * TPX;       // bytes of one pixel buffer: [channel][image of the chunk][128 pixels] = 24 KB
     constexpr int OFF_DW = 2 * LFI_MAX_IMAGES; // the integer offsets of every image (per-lane lookups by ds_read, not vector loads)
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * (PX_B / 4) + 2 * W_DW + OFF_DW];
+    // LDS (80 KB, two workgroups per CU): pixel buffers 0 and 1, weight buffer 0, and a third 24 KB region that is pixel buffer 2
+    // when the launch is one chunk and one view pass (three-deep ring, weights loaded once) and holds weight buffer 1 and the
+    // offset table otherwise (the one-chunk case reads the table before the first DMA into that region)
+    constexpr int THIRD_DW = 2 * (PX_B / 4) + W_DW;
+    static_assert(W_DW + OFF_DW <= PX_B / 4, "weight buffer 1 and the offset table must fit the third pixel buffer");
+    __shared__ __attribute__((aligned(16))) uint32_t lds[3 * (PX_B / 4) + W_DW];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,7 +76,7 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
     const size_t oplane_px = (size_t)W * (size_t)a.out_rows;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr_t)lds)));
     const size_t shift_stride = (size_t)H * a.planar_pitch; // one byte plane
-    int2 *off_table = reinterpret_cast<int2 *>(lds + 2 * (PX_B / 4) + 2 * W_DW);
+    int2 *off_table = reinterpret_cast<int2 *>(lds + THIRD_DW + W_DW);
     for(int g = threadIdx.x; g < a.n_images; g += 256)
     {
         const lfi_int2 o = a.focused[g];
@@ -82,7 +87,7 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
 
     auto issue_weights = [&](const int pass, const int k0, const int wb) {
         const int kc = min(KC, a.k_pad - k0);
-        const uint32_t w_addr = lds_base + 2 * PX_B + uint32_t(wb) * (W_DW * 4);
+        const uint32_t w_addr = lds_base + (wb ? THIRD_DW : 2 * (PX_B / 4)) * 4;
         for(int o = wave; 8 * o < kc; o += 4)
             if(lane < VPP)
                 dma16(a.w16s + (size_t)(a.v0 + pass * VPP + lane) * a.k_pad + k0 + 8 * o, w_addr + uint32_t(o) * (VPP * 16));
@@ -115,7 +120,7 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
         const int y = a.out_y0 + ty;
         const int x0 = (t - ty * tiles_x) * TPX;
         const int kc = min(KC, a.k_pad - k0);
-        const uint32_t dst = lds_base + uint32_t(pb) * PX_B;
+        const uint32_t dst = lds_base + (pb == 2 ? THIRD_DW * 4 : uint32_t(pb) * PX_B);
 #pragma unroll
         for(int j = 0; j < 6; j++)
         {
@@ -140,6 +145,55 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
     Pieces pieces = lookup(0);
     issue_weights(0, 0, 0);
     issue_pixels(t, 0, 0, pieces);
+
+    if(static_weights && ring3)
+    {
+        // ---- one chunk, one view pass: a ring of three pixel buffers, tiles fetched TWO ahead (24 KB per tile: with two
+        // buffers only 48 KB per CU would be in flight).  Stream of this wave's VMEM operations: … DMA(u+2) stores(u) DMA(u+3)
+        // stores(u+1) …, so tile u has landed when at most stores(u−2) + DMA(u+1) + stores(u−1) operations are outstanding.
+        const int kc = a.k_pad;
+        int n_dma = 0; // DMA instructions of this wave per tile
+#pragma unroll
+        for(int j = 0; j < 6; j++)
+            n_dma += 8 * ((wave + 4 * j) & 7) < kc ? 1 : 0;
+        if(t + G < n_tiles)
+            issue_pixels(t + G, 0, 1, pieces);
+        f32x16 acc3[MT][3]; // never cleared: the first MFMA of a tile takes a zero C operand
+        const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(lds + 2 * (PX_B / 4));
+        int buf3 = 0, st1 = 0, st2 = 0; // stores of the previous and of the one-before-previous epilogue
+        while(true)
+        {
+            const bool next_in_flight = t + G < n_tiles;
+            const int allowed = st2 + (next_in_flight ? n_dma : 0) + st1;
+            switch(min(allowed, 63) >> 3)
+            {
+                case 7: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+            __builtin_amdgcn_s_barrier(); // everybody's pieces of tile t have landed; everybody is done with tile t − 1's buffer
+            asm volatile("" ::: "memory");
+            const int buf_next2 = buf3 == 0 ? 2 : buf3 - 1; // (buf3 + 2) % 3 = the buffer tile t − 1 used
+            if(t + 2 * G < n_tiles)
+                issue_pixels(t + 2 * G, 0, buf_next2, pieces);
+
+            const uint8_t *col = reinterpret_cast<const uint8_t *>(lds + (buf3 == 2 ? THIRD_DW : buf3 * (PX_B / 4))) + wave * 32 + r + 8 * h * TPX;
+            unit_ten_bytes<MT, TPX, KC, true>(col, w_buf, r, h, kc, acc3);
+            const int ty = t / tiles_x;
+            st2 = st1;
+            st1 = store_tile<false, MT, NT_STORE, false>(a, acc3, a.v0, ty, (t - ty * tiles_x) * TPX + wave * 32, r, h, oplane_px);
+            if(!next_in_flight)
+                break;
+            t += G;
+            buf3 = buf3 == 2 ? 0 : buf3 + 1;
+        }
+        return;
+    }
 
     f32x16 acc[MT][3];
 #pragma unroll
@@ -193,39 +247,9 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
             }
         }
 
-        // ---- k-loop: as unit_ten (blend_core.hpp), the B operand assembled from bytes: image g of the chunk, channel c, at byte
-        // (c·64 + g)·128 + pixel of the buffer; this lane's pixel 32·wave + r, images 16 ks + 8 h + j
         const int kc = min(KC, a.k_pad - k0);
-        const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(lds + 2 * (PX_B / 4) + wbuf * W_DW);
-        const uint8_t *col = reinterpret_cast<const uint8_t *>(lds) + pbuf * PX_B + wave * 32 + r + 8 * h * TPX;
-#pragma unroll
-        for(int ks = 0; ks < KS; ks++)
-        {
-            if(16 * ks < kc)
-            {
-                half8 wfrag[MT];
-#pragma unroll
-                for(int m = 0; m < MT; m++)
-                    wfrag[m] = __builtin_bit_cast(half8, w_buf[(2 * ks + h) * VPP + m * 32 + r]);
-                u32x4 bc[3];
-#pragma unroll
-                for(int c = 0; c < 3; c++)
-#pragma unroll
-                    for(int q = 0; q < 4; q++)
-                    {
-                        const uint32_t lo = col[(c * KC + 16 * ks + 2 * q) * TPX], hi = col[(c * KC + 16 * ks + 2 * q + 1) * TPX];
-                        bc[c][q] = lo | (hi << 16); // two fp16 subnormals b·2^-24
-                    }
-#pragma unroll
-                for(int c = 0; c < 3; c++)
-                {
-                    const half8 bfrag = __builtin_bit_cast(half8, bc[c]);
-#pragma unroll
-                    for(int m = 0; m < MT; m++)
-                        acc[m][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[m], bfrag, acc[m][c], 0, 0, 0);
-                }
-            }
-        }
+        const u32x4 *w_buf = reinterpret_cast<const u32x4 *>(lds + (wbuf ? THIRD_DW : 2 * (PX_B / 4)));
+        unit_ten_bytes<MT, TPX, KC, false>(reinterpret_cast<const uint8_t *>(lds) + pbuf * PX_B + wave * 32 + r + 8 * h * TPX, w_buf, r, h, kc, acc);
 
         prev_stores = 0;
         if(k0 + KC >= a.k_pad) // last chunk of the tile's pass: epilogue

@@ -250,7 +250,7 @@ void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 
 // TEN_WM from the planar copy of the inputs (blend_planar.hpp) when launch_blend has validated it for this launch
 // (a.planar != nullptr: whole image, fixed focus), else blend_persist
-template <bool NT_STORE>
+template <bool NT_STORE, int RING3 = 1>
 void launch_planar(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
     if(!a.planar || all_focus)
@@ -262,7 +262,7 @@ void launch_planar(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     const int n_tiles = tiles_x * a.out_rows;
     const int passes = (a.v1 - a.v0 + 63) / 64;
     const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
-    hipLaunchKernelGGL((lfi::blend_planar<2, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
+    hipLaunchKernelGGL((lfi::blend_planar<2, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, RING3);
 }
 
 // wave-private pipelines (blend_wave.hpp) where they apply — fixed focus, one K-chunk, one view pass — else blend_persist
@@ -307,6 +307,7 @@ void launch_std_valu(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 const Variant kTenVariants[] = {
     {"planar_m2_nt", launch_planar<true>, true, false, true, true}, // blend_persist where blend_planar does not apply
     {"planar_m2", launch_planar<false>, true, false, true, true},
+    {"planar_ring2_nt", launch_planar<true, 0>, true, false, true, true},
     {"persist_m2_nt", launch_persist<false, 2, true>, true, false, true},
     {"persist_m2", launch_persist<false, 2, false>, true, false, true},
     {"wave_m2_nt", launch_wave<false, 2, true>, true, false, true},
