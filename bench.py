@@ -139,6 +139,7 @@ def main() -> int:
         ctx.set_stream(stream.cuda_stream)
         ctx.fill_synthetic(SEED)
         ctx.sync()
+        ctx.grid_modified()              # attached planes: announce that they are final
     ctx.set_params(hp)
     views = torch.empty((VIEWS_PER_GPU, out_rows_n, WIDTH, 4), dtype=torch.uint8, device=dev)
     ctx.attach_views(views.data_ptr(), views.numel())

@@ -12,7 +12,7 @@
 //
 // planar_build — once per change of the inputs (the context tracks them, include/lfi.h lfi_grid_modified): 12 byte planes per
 //                image from its RGBA plane.
-// blend_planar — the workgroup pipeline of blend_persist (fixed focus, whole image; any number of images and views): 24 LDS-DMA
+// blend_planar — the workgroup pipeline of blend_persist (fixed focus; any number of images and views; row windows): 24 LDS-DMA
 //                pieces of 8 runs × 128 bytes per unit, 6 per wave (a run per wave-sized tile would be 32 bytes: four times the
 //                cache-line requests per byte — measured slower than the RGBA kernel); LDS bytes [channel][image][128 pixels];
 //                the MFMA B operand is assembled from byte reads (a pixel byte IS the fp16 subnormal's mantissa).
@@ -25,6 +25,7 @@
 namespace lfi {
 
 // grid (ceil(pitch/1024), H, N): a thread writes one dword (4 consecutive bytes) of all 12 planes of its image row
+// H = rows HELD per plane (the whole image, or the input rows of a row window)
 __global__ void __launch_bounds__(256) planar_build(const uint8_t *__restrict__ grid, uint8_t *__restrict__ planar, const int W, const int H,
                                                     const int pitch, const int padx)
 {
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
     const int W = a.width, H = a.height;
     const size_t oplane_px = (size_t)W * (size_t)a.out_rows;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr_t)lds)));
-    const size_t shift_stride = (size_t)H * a.planar_pitch; // one byte plane
+    const size_t shift_stride = (size_t)a.in_rows * a.planar_pitch; // one byte plane: the rows this context holds
     int2 *off_table = reinterpret_cast<int2 *>(lds + THIRD_DW + W_DW);
     for(int g = threadIdx.x; g < a.n_images; g += 256)
     {
@@ -128,10 +129,10 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
             if(8 * (p & 7) >= kc)
                 continue; // wave-uniform: the chunk is shorter (its length is a multiple of 16)
             // the run starts at pixel x0 + ox: dword aligned in shift copy (x0 + ox + padx) & 3; the padding exceeds every offset
-            const int sy = clampi(y + pc.oy[j], 0, H - 1);
+            const int sy = clampi(y + pc.oy[j], 0, H - 1) - a.in_y0; // clamp in the full image, then index the held rows
             const int start = x0 + pc.ox[j] + a.planar_padx;
             const int k = start & 3;
-            dma16(a.planar + pc.plane0[j] + ((size_t)k * H + sy) * a.planar_pitch + (start - k) + 16 * (lane & 7), dst + uint32_t(p) * 1024u);
+            dma16(a.planar + pc.plane0[j] + ((size_t)k * a.in_rows + sy) * a.planar_pitch + (start - k) + 16 * (lane & 7), dst + uint32_t(p) * 1024u);
         }
     };
 

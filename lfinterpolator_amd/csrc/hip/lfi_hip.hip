@@ -249,7 +249,7 @@ void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 }
 
 // TEN_WM from the planar copy of the inputs (blend_planar.hpp) when launch_blend has validated it for this launch
-// (a.planar != nullptr: whole image, fixed focus), else blend_persist
+// (a.planar != nullptr: fixed focus), else blend_persist
 template <bool NT_STORE, int RING3 = 1>
 void launch_planar(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
@@ -365,10 +365,10 @@ dim3 pixel_grid_of(const lfi_ctx *c) { return pixel_grid(c); }
 int cu_count_of(const lfi_ctx *c) { return c->cu_count; }
 
 // Make the planar copy of the inputs valid for a fixed-focus launch with the current parameters; returns false (and leaves the
-// launch on the RGBA planes) when the copy may not be used: row window, inputs the library cannot track, absurd offsets.
+// launch on the RGBA planes) when the copy may not be used: inputs the library cannot track, absurd offsets.
 bool ensure_planar(lfi_ctx *c)
 {
-    if(c->windowed || !c->grid_tracked)
+    if(!c->grid_tracked)
         return false;
     const int reach = std::max(std::max(std::abs(c->fo_min[0]), std::abs(c->fo_max[0])), 0);
     if(reach > 4 * c->width + 4096)
@@ -380,7 +380,7 @@ bool ensure_planar(lfi_ctx *c)
         return true;
     const int padx = std::max(need, c->planar_padx);
     const int pitch = (c->width + 2 * padx + 15) / 16 * 16;
-    const size_t bytes = (size_t)c->n * 12 * c->height * pitch;
+    const size_t bytes = (size_t)c->n * 12 * c->in_rows * pitch; // the rows this context holds (a row window: band + halo)
     if(bytes != c->planar_bytes)
     {
         if(c->planar)
@@ -398,8 +398,8 @@ bool ensure_planar(lfi_ctx *c)
     }
     c->planar_padx = padx;
     c->planar_pitch = pitch;
-    hipLaunchKernelGGL(lfi::planar_build, dim3((pitch / 4 + 255) / 256, c->height, c->n), dim3(256), 0, c->stream, c->grid, c->planar,
-                       c->width, c->height, pitch, padx);
+    hipLaunchKernelGGL(lfi::planar_build, dim3((pitch / 4 + 255) / 256, c->in_rows, c->n), dim3(256), 0, c->stream, c->grid, c->planar,
+                       c->width, c->in_rows, pitch, padx);
     if(hipGetLastError() != hipSuccess)
         return false;
     c->planar_version = c->grid_version;
@@ -819,6 +819,8 @@ int lfi_set_row_window(lfi_ctx *ctx, int out_y0, int out_y1, int in_y0, int in_y
     ctx->grid_bytes = in_plane_bytes(ctx) * ctx->n;
     LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->grid), ctx->grid_bytes));
     ctx->own_grid = true;
+    ctx->grid_version++;
+    ctx->grid_tracked = true;
     return LFI_OK;
 }
 
