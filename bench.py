@@ -202,6 +202,10 @@ def main() -> int:
             "config": {"workload": f"{COLS}x{ROWS} LF @{WIDTH}x{HEIGHT}, {VIEWS_PER_GPU}-view -t trajectory per GPU, "
                                    f"-m {args.method}, -f {FOCUS} -a {ASPECT} -s {EFFECT:g}",
                        "views_per_gpu": VIEWS_PER_GPU, "images": n_images, "variant": args.variant,
+                       "inputs": ("resident in HBM before the timed region: RGBA planes + the planar alpha-free copy the TEN_WM kernel "
+                                  "reads (derived once per change of the inputs by planar_build, ~0.7 ms, DESIGN.md 4.1)"
+                                  if args.method == "TEN_WM" and args.variant in ("auto", "planar_m2_nt", "planar_m2", "planar_ring2_nt")
+                                  else "resident in HBM before the timed region: RGBA planes"),
                        "parallelism": (f"views sharded over {world} GPU(s), grid broadcast once ({'gloo rehearsal' if rehearse else 'RCCL'})"
                                        if args.shard == "views" else
                                        f"rows sharded over {world} GPU(s): {out_rows_n} output rows from {in_rows_n} input rows on rank 0, "
