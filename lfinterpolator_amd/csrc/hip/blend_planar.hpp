@@ -17,6 +17,15 @@
 //                cache-line requests per byte — measured slower than the RGBA kernel); LDS bytes [channel][image][128 pixels];
 //                the MFMA B operand is assembled from byte reads (a pixel byte IS the fp16 subnormal's mantissa).
 // Arithmetic, weights, operand maps and epilogue are those of blend_persist / blend_wave (blend_core.hpp): identical output bytes.
+//
+// STDF = true — the STD method (exact fp32 fmaf chain, src/kernels.cu:292-310) at TEN_WM speed for launches of one chunk:
+// the chain's result differs from the exact sum S by at most N·2^-16 (N ≤ 64 roundings of half an ulp of a value below 512 —
+// the host checks that every view's weights are non-negative and sum to at most 2), and so does the fp16-MFMA accumulation of
+// the same exactly-representable products by at most N·2^-15 even if every one of its additions truncated.  Wherever the MFMA
+// sum is farther than std_band (≥ the two bounds together, plus a margin) from every half-integer, rounding it gives the
+// byte the chain gives; the few per cent of (pixel, view, channel) sums inside the band are queued in LDS and recomputed with
+// the chain itself (v_fma_f32, images ascending) from the pixel bytes and weights still resident in LDS, 64 at a time, and
+// patched with byte stores behind the tile's dword stores.  Bit-exact against the oracle like blend_wave<STD> (same tests).
 // Replaces Kernels::Tensors::process<false> (reference src/kernels.cu:398-461).
 #pragma once
 
@@ -53,10 +62,130 @@ __global__ void __launch_bounds__(256) planar_build(const uint8_t *__restrict__ 
         }
 }
 
+// STDF epilogue of one wave's 32 pixels × (MT·32 views from vbase): acc holds S·2^-9 (fp16 MFMA of pixel subnormals and ×2^15
+// weights).  Stores round(S) for every valid output like store_tile<STD>, queues the (lane, m, channel, e) whose S lies within
+// a.std_band of a half-integer, and recomputes those with the reference's fmaf chain from LDS (px = this wave's pixel bytes
+// [channel][image][TPX], wh = the weight fragments as halves [k-octet][view][8], ×2^15), patching single bytes.  Returns the
+// number of store instructions issued; clears acc.
+template <int MT, bool NT_STORE, int KC, int TPX>
+__device__ __forceinline__ int store_tile_filtered(const KernelArgs &a, f32x16 (&acc)[MT][3], const int vbase, const int y, const int xw,
+                                                   const int lane, const size_t oplane_px, const uint8_t *px, const uint16_t *wh,
+                                                   const int kc, uint16_t *queue)
+{
+    constexpr int VPP = MT * 32;
+    const int W = a.width, r = lane & 31, h = lane >> 5;
+    int n_st = 0, count = 0; // count: queued entries (wave-uniform)
+    uint8_t *plane0 = a.views + ((size_t)vbase * oplane_px + (size_t)y * W + xw) * 4;
+    auto patch = [&](const int n) { // recompute the first n ≤ 64 queued sums exactly, one per lane
+        const uint32_t code = queue[lane < n ? lane : 0];
+        const int src = code & 63, e = (code >> 6) & 15, c = (code >> 10) & 3, m = (code >> 12) & 1;
+        const int vrel = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (src >> 5), pxl = src & 31;
+        const uint8_t *pb = px + (size_t)(c * KC) * TPX + pxl;
+        const u32x4 *wb = reinterpret_cast<const u32x4 *>(wh) + vrel; // this view's eight ×2^15 halves of a k-octet
+        // the chain on the ×2^15 weights: a power-of-two scaling commutes with every rounding (no overflow: sums < 2^24), so
+        // s15 = 2^15 · (the reference's running sum) exactly
+        float s15 = 0.0f;
+        for(int o = 0; 8 * o < kc; o++)
+        {
+            const u32x4 w8 = wb[o * VPP];
+#pragma unroll
+            for(int j = 0; j < 8; j++)
+            {
+                const uint32_t pair = w8[j >> 1];
+                const float w = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(j & 1 ? pair >> 16 : pair)));
+                s15 = __builtin_fmaf(static_cast<float>(pb[(8 * o + j) * TPX]), w, s15); // addWeighted, src/kernels.cu:292-299
+            }
+        }
+        const uint32_t byte = __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; // (unsigned char)__float2int_rn(sum)
+        if(lane < n)
+            plane0[((size_t)vrel * oplane_px + pxl) * 4 + c] = static_cast<uint8_t>(byte);
+        n_st++;
+    };
+    // acc = S·2^-9: adding 2^14 rounds it (RN-even) to a multiple of 2^-9, i.e. S to an integer, left in the low mantissa bits
+    const float inside = (0.5f - a.std_band) * 0x1p-9f;
+    static_assert(MT <= 2, "the per-lane flag words hold 2 × 16 accumulator registers per channel");
+    uint32_t flagged[3] = {0u, 0u, 0u}; // per lane and channel: bit m·16 + e ↔ the sum in acc[m][c][e] needs the chain
+#pragma unroll
+    for(int m = 0; m < MT; m++)
+    {
+        const int view_m = vbase + m * 32;
+        const int nvalid = min(a.v1 - view_m, 32);
+        if(nvalid > 0 && xw < W)
+        {
+            const bool lane_x_ok = xw + r < W;
+#pragma unroll
+            for(int e = 0; e < 16; e++)
+            {
+                const int vrow = (e & 3) + 8 * (e >> 2); // + 4h per half-wave
+                if(vrow >= nvalid) // wave-uniform
+                    continue;
+                const bool valid = lane_x_ok && vrow + 4 * h < nvalid;
+                uint32_t bits[3];
+#pragma unroll
+                for(int c = 0; c < 3; c++)
+                {
+                    const float t = acc[m][c][e] + 16384.0f;
+                    bits[c] = __builtin_bit_cast(uint32_t, t);
+                    if(valid && __builtin_fabsf(acc[m][c][e] - (t - 16384.0f)) > inside)
+                        flagged[c] |= 1u << (m * 16 + e);
+                }
+                const uint32_t rg = __builtin_amdgcn_perm(bits[1], bits[0], 0x0c0c0400u); // [R, G, 0, 0]
+                const uint32_t rgba = __builtin_amdgcn_perm(bits[2], rg, 0x0d040100u);  // [R, G, B, 0xff]
+                uint32_t *out = reinterpret_cast<uint32_t *>(plane0 + ((size_t)(m * 32 + vrow + 4 * h) * oplane_px + r) * 4);
+                n_st++;
+                if(valid)
+                {
+                    if constexpr(NT_STORE)
+                        __builtin_nontemporal_store(rgba, out);
+                    else
+                        *out = rgba;
+                }
+            }
+        }
+#pragma unroll
+        for(int c = 0; c < 3; c++)
+#pragma unroll
+            for(int e = 0; e < 16; e++)
+                acc[m][c][e] = 0.0f;
+    }
+    // compact the flagged sums of the wave into the queue, one per lane and round, and recompute them 64 at a time
+    while(true)
+    {
+        const bool any = (flagged[0] | flagged[1] | flagged[2]) != 0u;
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(any);
+        if(mask == 0ull)
+            break;
+        if(any)
+        {
+            const int c = flagged[0] ? 0 : (flagged[1] ? 1 : 2);
+            const uint32_t word = c == 0 ? flagged[0] : (c == 1 ? flagged[1] : flagged[2]);
+            const int b = __builtin_ctz(word);
+            const uint32_t rest = word & (word - 1u);
+            flagged[0] = c == 0 ? rest : flagged[0];
+            flagged[1] = c == 1 ? rest : flagged[1];
+            flagged[2] = c == 2 ? rest : flagged[2];
+            const int ahead = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+            queue[count + ahead] = static_cast<uint16_t>(lane | ((b & 15) << 6) | (c << 10) | ((b >> 4) << 12));
+        }
+        count += __builtin_popcountll(mask);
+        if(count >= 64)
+        {
+            patch(64);
+            const uint16_t tail = queue[64 + (lane < count - 64 ? lane : 0)];
+            if(lane < count - 64)
+                queue[lane] = tail;
+            count -= 64;
+        }
+    }
+    if(count > 0)
+        patch(count);
+    return n_st;
+}
+
 // Units as in blend_persist: (tile, view pass, chunk of ≤ 64 images); the pixel bytes of a tile stay in LDS for every view
 // pass when the image stack fits one chunk; the weight fragments are fetched per unit — or once per workgroup when there is a
 // single chunk and a single pass (config 2, every bench step).
-template <int MT, bool NT_STORE>
+template <int MT, bool NT_STORE, bool STDF = false>
 __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes, const int ring3)
 {
     constexpr int KC = 64, VPP = MT * 32, TPX = 128;
@@ -67,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
     // when the launch is one chunk and one view pass (three-deep ring, weights loaded once) and holds weight buffer 1 and the
     // offset table otherwise (the one-chunk case reads the table before the first DMA into that region)
     constexpr int THIRD_DW = 2 * (PX_B / 4) + W_DW;
-    static_assert(W_DW + OFF_DW <= PX_B / 4, "weight buffer 1 and the offset table must fit the third pixel buffer");
+    static_assert(W_DW + OFF_DW + 256 <= PX_B / 4, "weight buffer 1, the offset table and the STDF queues must fit the third pixel buffer");
     __shared__ __attribute__((aligned(16))) uint32_t lds[3 * (PX_B / 4) + W_DW];
 
     const int lane = threadIdx.x & 63;
@@ -147,7 +276,7 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
     issue_weights(0, 0, 0);
     issue_pixels(t, 0, 0, pieces);
 
-    if(static_weights && ring3)
+    if(static_weights && ring3 && !STDF)
     {
         // ---- one chunk, one view pass: a ring of three pixel buffers, tiles fetched TWO ahead (24 KB per tile: with two
         // buffers only 48 KB per CU would be in flight).  Stream of this wave's VMEM operations: … DMA(u+2) stores(u) DMA(u+3)
@@ -256,7 +385,13 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
         if(k0 + KC >= a.k_pad) // last chunk of the tile's pass: epilogue
         {
             const int ty = t / tiles_x;
-            prev_stores = store_tile<false, MT, NT_STORE, true>(a, acc, a.v0 + pass * VPP, ty, (t - ty * tiles_x) * TPX + wave * 32, r, h, oplane_px);
+            if constexpr(STDF)
+                prev_stores = store_tile_filtered<MT, NT_STORE, KC, TPX>(
+                    a, acc, a.v0 + pass * VPP, ty, (t - ty * tiles_x) * TPX + wave * 32, lane, oplane_px,
+                    reinterpret_cast<const uint8_t *>(lds) + pbuf * PX_B + wave * 32, reinterpret_cast<const uint16_t *>(w_buf), kc,
+                    reinterpret_cast<uint16_t *>(lds + THIRD_DW + W_DW + OFF_DW) + wave * 128);
+            else
+                prev_stores = store_tile<false, MT, NT_STORE, true>(a, acc, a.v0 + pass * VPP, ty, (t - ty * tiles_x) * TPX + wave * 32, r, h, oplane_px);
         }
         if(!have_next)
             break;

@@ -74,6 +74,7 @@ struct lfi_ctx
     lfi_float2 *d_offsets = nullptr;
     uint16_t *d_w16 = nullptr, *d_w16s = nullptr;
     bool weights_scalable = false; // every weight finite and in [0, 2): the ×2^15 copy is exact and the packed epilogue valid
+    bool weights_sum_ok = false;   // … and every view's weights sum to at most 2: blend_planar<STDF>'s error bounds hold (sums < 512)
     float *d_w32 = nullptr, *d_w32t = nullptr;
     int32_t *d_ids = nullptr;
     float focus = 0, range = 0;
@@ -163,6 +164,9 @@ KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
     a.v1 = v1;
     a.n_focus_ids = c->n_focus_ids;
     a.planar = nullptr; // set by launch_blend when the copy is valid for this launch
+    // blend_planar<STDF>: chain bound N·2^-16 (half an ulp below 512 per fmaf) + MFMA accumulation bound N·2^-15 (a whole ulp per
+    // addition, as if each truncated) + 2^-11 of margin
+    a.std_band = float(c->n) * (0x1p-16f + 0x1p-15f) + 0x1p-11f;
     a.planar_pitch = c->planar_pitch;
     a.planar_padx = c->planar_padx;
     a.fo_min_x = c->fo_min[0];
@@ -280,6 +284,22 @@ void launch_wave(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     hipLaunchKernelGGL((lfi::blend_wave<STD, MT, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles);
 }
 
+// STD through blend_planar<STDF> (MFMA sum + exact recomputation inside the rounding band) when launch_blend has validated the
+// planar copy and the weights for it, else the exact-fp32 MFMA kernels
+void launch_std_filtered(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    if(!a.planar || all_focus || a.k_pad > 64)
+    {
+        launch_wave<true, 2, true>(c, a, all_focus);
+        return;
+    }
+    const int tiles_x = (a.width + 127) / 128;
+    const int n_tiles = tiles_x * a.out_rows;
+    const int passes = (a.v1 - a.v0 + 63) / 64;
+    const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    hipLaunchKernelGGL((lfi::blend_planar<2, true, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, 0);
+}
+
 template <int PXL, int MT>
 void launch_std_mfma(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
@@ -323,6 +343,7 @@ const Variant kTenVariants[] = {
     {"direct_p1m1", launch_ten_direct<1, 1>, false, true},
 };
 const Variant kStdVariants[] = {
+    {"filtered_m2_nt", launch_std_filtered, false, false, true, true}, // blend_wave / blend_persist where it does not apply
     {"wave_m2_nt", launch_wave<true, 2, true>, false, false, true}, // blend_persist where blend_wave does not apply
     {"persist_m2_nt", launch_persist<true, 2, true>, false, false, true},
     {"persist_m1_nt", launch_persist<true, 1, true>, false, false, true},
@@ -411,8 +432,12 @@ bool ensure_planar(lfi_ctx *c)
 // assembly repeats per view pass).
 bool wants_planar(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
 {
-    return method == LFI_METHOD_TEN_WM && !all_focus && !a.prequant && kTenVariants[c->ten_variant].planar && c->weights_scalable &&
-           !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) && a.v1 - a.v0 <= std::max(c->n, 64);
+    if(all_focus || a.prequant || !c->weights_scalable || a.v1 - a.v0 > std::max(c->n, 64))
+        return false;
+    if(method == LFI_METHOD_TEN_WM)
+        return kTenVariants[c->ten_variant].planar && !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH);
+    // STD: blend_planar<STDF> — one chunk, and weights for which its error bounds hold
+    return method == LFI_METHOD_STD && kStdVariants[c->std_variant].planar && c->weights_sum_ok && a.k_pad <= 64;
 }
 
 int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
@@ -1035,6 +1060,14 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
             w32[(size_t)v * k_pad + g] = f;
             w32t[(size_t)g * v_pad + v] = f;
         }
+    bool sums_ok = scalable;
+    for(int v = 0; v < V && sums_ok; v++)
+    {
+        double sum = 0;
+        for(int g = 0; g < n; g++)
+            sum += w32[(size_t)v * k_pad + g];
+        sums_ok = sum <= 2.0;
+    }
     if(p->n_focus_ids)
         std::memcpy(blob.data() + off_ids, p->focus_map_ids, sizeof(int32_t) * p->n_focus_ids);
 
@@ -1047,6 +1080,7 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     ctx->d_w16 = reinterpret_cast<uint16_t *>(base + off_w16);
     ctx->d_w16s = reinterpret_cast<uint16_t *>(base + off_w16s);
     ctx->weights_scalable = scalable;
+    ctx->weights_sum_ok = sums_ok;
     ctx->d_w32 = reinterpret_cast<float *>(base + off_w32);
     ctx->d_w32t = reinterpret_cast<float *>(base + off_w32t);
     ctx->d_ids = reinterpret_cast<int32_t *>(base + off_ids);
