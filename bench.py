@@ -218,8 +218,9 @@ def main() -> int:
                          "algorithmic_bytes_per_launch": b_alg, "frac_of_measured_copy_6290": achieved / 6290.0,
                          "mfma_frac_of_2500_tflops": f_alg / t_launch / 2.5e15},
         }
-        if args.method == "STD":
-            # the exact-fp32 path is bound by the fp32 matrix pipe: F_alg = 6·N·V·W·H flops per launch against
+        if args.method == "STD" and args.variant not in ("auto", "filtered_m2_nt"):
+            # the exact-fp32 MFMA kernels are bound by the fp32 matrix pipe (the default STD kernel computes on the
+            # fp16 matrix pipe and recomputes the sums near x.5 with the fmaf chain: HBM-bound like TEN_WM): F_alg = 6·N·V·W·H flops per launch against
             # the dense fp32 matrix peak (157.3 TFLOP/s: 256 CUs × 4 SIMDs × 64 flop/cycle × 2.4 GHz)
             tflops = f_alg / t_launch / 1e12
             line["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",

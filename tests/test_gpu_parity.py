@@ -463,3 +463,51 @@ def test_random_shapes_default_kernels(case, gpu, oracle_c):
         assert (after[v0:v1] == want_std[v0:v1]).all()
         assert (after[:v0] == before[:v0]).all() and (after[v1:] == before[v1:]).all()
     ctx.close()
+
+
+def _f16_bits(x):
+    return np.asarray(x, np.float16).view(np.uint16)
+
+
+@pytest.mark.parametrize("kind", ["ties_everywhere", "flat_images", "sum_1p999", "sum_above_2", "tiny_weights"])
+def test_std_rounding_band_adversarial(kind, gpu, oracle_c):
+    """STD through blend_planar<STDF> decides most bytes from the MFMA sum and recomputes those near x.5 with the chain.  Inputs
+    built to sit in or on the band: exact ties for every pixel (two weights of 0.5, odd pixel differences) — every lane queues
+    many sums —, flat images, weights summing to just under 2 (sums up to 510), above 2 (the exact-MFMA kernel must take over),
+    and weights deep in the fp16 subnormals.  Bit-exact against the oracle in every case."""
+    cols, rows, W, H, V = 8, 8, 200, 7, 64
+    n = cols * rows
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.1, 0.0, 3.0, 1.783, V)
+    rng = np.random.default_rng(5)
+    lf = oracle_c.synthetic_lf(n, W, H, 9)
+    w = np.zeros((V, n), np.float32)
+    if kind == "ties_everywhere":
+        for v in range(V):
+            a, b = rng.choice(n, 2, replace=False)
+            w[v, a] = w[v, b] = 0.5
+        lf[..., :3] = (lf[..., :3] // 2) * 2          # even values …
+        lf[::2, :, :, :3] += 1                         # … and odd ones in every other image: half of the pairs tie at x.5
+    elif kind == "flat_images":
+        w = np.abs(rng.standard_normal((V, n))).astype(np.float32)
+        w /= w.sum(1, keepdims=True)
+        lf[..., :3] = rng.integers(0, 256, (n, 1, 1, 3), dtype=np.uint8)
+    elif kind == "sum_1p999":
+        w = np.abs(rng.standard_normal((V, n))).astype(np.float32)
+        w *= 1.99 / w.sum(1, keepdims=True)
+    elif kind == "sum_above_2":
+        w = np.abs(rng.standard_normal((V, n))).astype(np.float32)
+        w *= 2.6 / w.sum(1, keepdims=True)
+    else:
+        w = (rng.random((V, n)) * 3e-5).astype(np.float32)   # fp16 subnormals and the smallest normals
+        w[:, 0] = 0.75
+    hp.weights = _f16_bits(w)
+    lf[..., 3] = 255
+    ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    want = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)
+    for variant in ("auto", "wave_m2_nt", "persist_m2_nt"):
+        ctx.set_variant("STD", variant)
+        ctx.render("STD")
+        ctx.sync()
+        got = ctx.download_views()
+        assert (got == want).all(), (kind, variant, int((got != want).sum()))
+    ctx.close()
