@@ -11,11 +11,20 @@ One "step" = one launch of the blend kernel over the synthetic grid resident in 
 [64r, 64r+64) — the path shards over views with no data-path collective (weak scaling: per-GPU work is fixed); the
 input grid is generated on rank 0 and broadcast ONCE over RCCL/xGMI before the timed region.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
   roofline     — HBM roofline of the blend kernel: algorithmic bytes 4·W·H·(N_images + V) per launch ÷ the kernel's
-                 average launch time measured with HIP events on the launch stream (through the C-ABI timer);
+                 average launch time measured with HIP events on the launch stream (through the C-ABI timer); `frac` is on
+                 those algorithmic bytes (SURVEY.md §8(d)), `frac_moved` on the bytes the layouts in use actually need;
   cpu_baseline — the CPU oracle (a port of the reference's STD arithmetic) timed on the host cores on the same
-                 workload (N = 1 only).  oracle/ is used here ONLY as that baseline, never in the GPU path.
+                 workload (N = 1 only).  oracle/ is used here ONLY as that baseline, never in the GPU path;
+  also         — (N = 1) the other BASELINE configurations and methods, timed in the same run after the headline step:
+                 config 3 (15×15 @1080p, 45 views), config 4 per rank and whole, config 5 fixed focus and end to end
+                 (focus map + all-focus render), STD and the non-tensor wavefront kernel at config 2 — each with ms,
+                 algorithmic bytes, roofline fraction and the kernel that ran.
+
+Other modes:  --config 4  strong-scaled BASELINE config 4 (8×8 @4K, one 256-view trajectory split over the GPUs);
+              --distribute allgather  every rank generates 1/G of the images, one all-gather instead of the broadcast;
+              --shard rows  one render split into row bands (no collective).
 """
 from __future__ import annotations
 
@@ -28,32 +37,154 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-COLS, ROWS, WIDTH, HEIGHT = 8, 8, 1920, 1080
-VIEWS_PER_GPU = 64
-TRAJECTORY, FOCUS, ASPECT, EFFECT = "0.0,0.0,1.0,1.0", 0.23, 1.783, 3.0   # reference README.md:7
 SEED = 0x1F1F
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-FP32_MATRIX_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (= fp32 vector) peak: 256 CUs x 4 SIMDs x 64 flop/cycle x 2.4 GHz
+FP32_PEAK_TFLOPS = 157.3  # dense fp32 vector = fp32 matrix peak: 256 CUs x 4 SIMDs x 64 flop/cycle x 2.4 GHz
+F16_MFMA_PEAK_TFLOPS = 2500.0
+
+# BASELINE.json configs (index = position in `configs`, 1-based like SURVEY.md §8(d)); parameters: reference README.md:7 for the
+# 8×8 grids, scripts/focusMapCompare.sh:1-5 (-s 7, focus / range / aspect table) for the focus sweep of config 5
+CONFIGS = {
+    2: dict(cols=8, rows=8, W=1920, H=1080, views=64, traj="0.0,0.0,1.0,1.0", focus=0.23, rng=0.0, aspect=1.783, effect=3.0),
+    3: dict(cols=15, rows=15, W=1920, H=1080, views=45, traj="0,0.5,1,0.5", focus=0.06, rng=0.0, aspect=2.276, effect=3.0),
+    4: dict(cols=8, rows=8, W=3840, H=2160, views=256, traj="0.0,0.0,1.0,1.0", focus=0.23, rng=0.0, aspect=1.783, effect=3.0),
+    5: dict(cols=15, rows=15, W=3840, H=2160, views=64, traj="0.071,0.071,0.93,0.93", focus=0.22, rng=0.17, aspect=1.783, effect=7.0),
+}
+TEN_PLANAR_VARIANTS = ("auto", "planar_m2_nt", "planar_m2", "planar_ring2_nt")
 
 
-def cpu_baseline(hp, threads: int) -> dict:
+def cpu_baseline(cfg, hp, threads: int) -> dict:
     """The oracle's scalar STD blend on one full step of the same workload, on `threads` host cores."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle import lfi_oracle_c as oc
     oc.build()
-    n = COLS * ROWS
-    lf = np.empty((n, HEIGHT, WIDTH, 4), dtype=np.uint8)
+    n, W, H = cfg["cols"] * cfg["rows"], cfg["W"], cfg["H"]
+    lf = np.empty((n, H, W, 4), dtype=np.uint8)
     with ThreadPoolExecutor(max_workers=threads) as ex:
-        list(ex.map(lambda g: lf.__setitem__(g, oc.synthetic_plane(g, WIDTH, HEIGHT, SEED)), range(n)))
+        list(ex.map(lambda g: lf.__setitem__(g, oc.synthetic_plane(g, W, H, SEED)), range(n)))
     t0 = time.perf_counter()
     oc.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, threads=threads)
     dt = time.perf_counter() - t0
     v = hp.weights.shape[0]
     return {"value": v / dt, "unit": "views/s", "cores": threads, "kind": "port",
-            "sample": f"1 step: {v} views of {WIDTH}x{HEIGHT} from {n} images, scalar fp32 FMA weighted mean "
+            "sample": f"1 step: {v} views of {W}x{H} from {n} images, scalar fp32 FMA weighted mean "
                       f"(oracle STD), {dt:.2f} s wall",
-            "gpix_per_s": v * WIDTH * HEIGHT / dt / 1e9}
+            "gpix_per_s": v * W * H / dt / 1e9}
+
+
+def b_alg(W, rows_in, n_images, rows_out, views):
+    """every RGBA8 input plane read once, every RGBA8 output plane written once."""
+    return 4.0 * W * (rows_in * n_images + rows_out * views)
+
+
+def timed(ctx, fn, iters: int, warm: int = 3) -> float:
+    """ms per call of fn(): HIP events on the context's launch stream around `iters` back-to-back calls."""
+    for _ in range(warm):
+        fn()
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(iters):
+        fn()
+    return ctx.timer_stop() / iters
+
+
+def also_table(L, device_index: int, iters: int, layout: str) -> dict:
+    """The rest of BASELINE.json's configurations on ONE GPU, after the headline step (HIP-event times, inputs resident)."""
+    out = {}
+
+    def entry(cfg, ms, views, kernel, note=None, flops_bound=None, n_images=None, in_bytes_extra=0.0):
+        n = n_images if n_images is not None else cfg["cols"] * cfg["rows"]
+        ba = b_alg(cfg["W"], cfg["H"], n, cfg["H"], views) + in_bytes_extra
+        fa = 6.0 * n * views * cfg["W"] * cfg["H"]
+        e = {"workload": f"{cfg['cols']}x{cfg['rows']} LF @{cfg['W']}x{cfg['H']}, {views} views", "kernel": kernel, "ms": ms,
+             "views_per_s": views / ms * 1e3, "algorithmic_bytes": ba, "hbm_gbs": ba / ms / 1e6, "frac": ba / ms / 1e6 / HBM_PEAK_GBS}
+        if flops_bound:
+            e["bound"] = "fp32"
+            e["fp32_tflops"] = fa / ms / 1e9
+            e["fp32_frac"] = fa / ms / 1e9 / FP32_PEAK_TFLOPS
+        if note:
+            e["note"] = note
+        return e
+
+    def make_ctx(cfg, views=None, rng=None):
+        ctx = L.Context(device_index)
+        ctx.set_grid(cfg["cols"], cfg["rows"], cfg["W"], cfg["H"])
+        ctx.fill_synthetic(SEED)
+        hp = L.build_params(cfg["cols"], cfg["rows"], cfg["W"], cfg["H"], cfg["traj"], cfg["focus"], cfg["rng"] if rng is None else rng,
+                            cfg["effect"], cfg["aspect"], views or cfg["views"])
+        ctx.set_params(hp)
+        return ctx, hp
+
+    # ---- config 2: the reference-layout (RGBA) output, STD, the non-tensor wavefront kernel ---------------------------------------
+    c2 = CONFIGS[2]
+    ctx, hp = make_ctx(c2)
+    if layout != "rgba":
+        ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
+        out["config2_ten_wm_rgba_views"] = entry(c2, ms, 64, ctx.last_kernel_name(), "views stored as RGBA planes (the reference's layout)")
+    ms = timed(ctx, lambda: ctx.render("STD"), iters)
+    out["config2_std"] = entry(c2, ms, 64, ctx.last_kernel_name(), "bit-exact STD (fp16 MFMA sum + exact fmaf chain inside the rounding band)")
+    ctx.set_variant("STD", "wave_m2_nt")
+    ms = timed(ctx, lambda: ctx.render("STD"), iters)
+    out["config2_std_exact_mfma"] = entry(c2, ms, 64, ctx.last_kernel_name(), "exact fp32 on v_mfma_f32_32x32x2_f32", flops_bound=True)
+    ctx.set_variant("STD", "valu")
+    ms = timed(ctx, lambda: ctx.render("STD"), max(2, iters // 4), warm=1)
+    out["config2_std_valu"] = entry(c2, ms, 64, ctx.last_kernel_name(), "the non-tensor wavefront kernel (v_fma_f32 chain)", flops_bound=True)
+    ctx.close()
+
+    # ---- config 3: 15×15 @1080p, 45-view quilt -------------------------------------------------------------------------------------
+    c3 = CONFIGS[3]
+    ctx, hp = make_ctx(c3)
+    if layout != "rgba":
+        ctx.set_output_layout(layout)
+    ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
+    out["config3"] = entry(c3, ms, 45, ctx.last_kernel_name())
+    ctx.close()
+
+    # ---- config 4: 8×8 @4K, per rank (32 of 256 views) and whole (256 views on this GPU) -------------------------------------------
+    c4 = CONFIGS[4]
+    hp_r, v0, v1 = L.rank_params(c4["cols"], c4["rows"], c4["W"], c4["H"], c4["traj"], c4["focus"], 0.0, c4["effect"], c4["aspect"], 256, 8, 3)
+    ctx = L.Context(device_index)
+    ctx.set_grid(c4["cols"], c4["rows"], c4["W"], c4["H"])
+    ctx.fill_synthetic(SEED)
+    ctx.set_params(hp_r)
+    if layout != "rgba":
+        ctx.set_output_layout(layout)
+    ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
+    out["config4_rank"] = entry(c4, ms, v1 - v0, ctx.last_kernel_name(), f"rank 3 of 8: views [{v0},{v1}) of the 256-view trajectory")
+    hp_all = L.build_params(c4["cols"], c4["rows"], c4["W"], c4["H"], c4["traj"], c4["focus"], 0.0, c4["effect"], c4["aspect"], 256)
+    ctx.set_params(hp_all)
+    if layout != "rgba":
+        ctx.set_output_layout(layout)
+    ms = timed(ctx, lambda: ctx.render("TEN_WM"), max(2, iters // 2))
+    out["config4_whole_1gpu"] = entry(c4, ms, 256, ctx.last_kernel_name(), "the whole 256-view trajectory on one GPU (inputs read once)")
+    ctx.close()
+
+    # ---- config 5: 15×15 @4K: fixed focus, and end to end = focus map (estimate + filter) + all-focus render, MFMA vs STD -----------
+    c5 = CONFIGS[5]
+    ctx, hp = make_ctx(c5)
+    if layout != "rgba":
+        ctx.set_output_layout(layout)
+    ms = timed(ctx, lambda: ctx.render("TEN_WM"), max(2, iters // 2))
+    out["config5_fixed_focus"] = entry(c5, ms, 64, ctx.last_kernel_name())
+    ctx.set_output_layout("rgba")
+    map_in = 4.0 * c5["W"] * c5["H"] * len(hp.focus_map_ids)          # the ≤32 sampled planes, read once by the estimate
+    map_io = 4.0 * c5["W"] * c5["H"] * 3                                # map 0 written + read, map 1 written
+    ms_map = timed(ctx, lambda: ctx.focus_map(), max(2, iters // 4), warm=1)
+    out["config5_focus_map"] = {"workload": "15x15 LF @3840x2160, focus map (estimate over 32 views x 32 candidates x 9 taps + filter)",
+                                "kernel": "focus_factored passes + focus_filter", "ms": ms_map,
+                                "algorithmic_bytes": map_in + map_io, "frac": (map_in + map_io) / ms_map / 1e6 / HBM_PEAK_GBS,
+                                "note": "bound by VALU issue / L2 (DESIGN.md 4.3), not HBM: the fraction is reported for completeness"}
+    for method in ("TEN_WM", "STD"):
+        ms_r = timed(ctx, lambda: ctx.render(method, all_focus=True), max(2, iters // 4), warm=1)
+        k = ctx.last_kernel_name()
+        ms_e = timed(ctx, lambda: (ctx.focus_map(), ctx.render(method, all_focus=True)), max(2, iters // 4), warm=1)
+        key = "config5_allfocus_" + method.lower()
+        out[key + "_render"] = entry(c5, ms_r, 64, k, "all-focus render from a resident focus map", flops_bound=(method == "STD"))
+        out[key + "_end_to_end"] = entry(c5, ms_e, 64, "focus map + " + k, "lfi_focus_map + all-focus render per iteration (-r 0.17)",
+                                         in_bytes_extra=map_in + map_io, flops_bound=(method == "STD"))
+    ctx.close()
+    return out
 
 
 def main() -> int:
@@ -63,11 +194,21 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--method", default="TEN_WM", choices=["TEN_WM", "STD"])
     ap.add_argument("--variant", default="auto")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4],
+                    help="2 (default): BASELINE config 2 per GPU, weak-scaled — the contract's run; 4: BASELINE config 4, strong-scaled — "
+                         "ONE 256-view trajectory @4K split over the GPUs (V/G views per rank), every rank holds the whole 8x8 grid")
+    ap.add_argument("--distribute", default="broadcast", choices=["broadcast", "allgather"],
+                    help="how the grid reaches every GPU before the timed region: broadcast from rank 0 (north_star), or every rank "
+                         "produces 1/G of the images and ONE all-gather assembles them (each xGMI link carries 1/G: SURVEY.md §5)")
+    ap.add_argument("--layout", default="rgba", choices=["rgba", "planar"],
+                    help="device layout of the rendered views: rgba = the reference's RGBA planes; planar = alpha-free byte planes "
+                         "(alpha is the constant 255 — src/kernels.cu:393 — and is re-created on download)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the table of the other BASELINE configurations (N = 1 only)")
+    ap.add_argument("--also-iters", type=int, default=12)
     ap.add_argument("--shard", default="views", choices=["views", "rows"],
-                    help="views (default, the contract's weak-scaling run): 64 views per GPU, every GPU holds the whole grid; "
-                         "rows: strong scaling of ONE 64-view render — each GPU renders a band of rows and holds only the "
-                         "input rows the band's warp reaches (SURVEY.md §8(f).2)")
+                    help="views (default): every GPU holds the whole grid and renders its views; rows: strong scaling of ONE render — each "
+                         "GPU renders a band of rows and holds only the input rows the band's warp reaches (SURVEY.md §8(f).2)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed launches during set-up, before the W warm-up steps, so that the clocks have ramped "
                          "(with 5 warm-up launches = 1 ms of work the first timed launches still run at idle clocks)")
@@ -105,31 +246,60 @@ def main() -> int:
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    cfg = CONFIGS[args.config]
+    COLS, ROWS, WIDTH, HEIGHT = cfg["cols"], cfg["rows"], cfg["W"], cfg["H"]
     n_images = COLS * ROWS
+    strong = args.config == 4 or args.shard == "rows"
+    if args.config == 4:
+        total_views = cfg["views"]                       # one trajectory, split over the ranks
+        if total_views % world:
+            print("bench.py: --config 4 needs a GPU count that divides 256", file=sys.stderr)
+            return 2
+        views_per_gpu = total_views // world
+    else:
+        views_per_gpu = cfg["views"]
+        total_views = views_per_gpu * (world if args.shard == "views" else 1)
+
     ctx = L.Context(device_index)
     ctx.set_grid(COLS, ROWS, WIDTH, HEIGHT)
     stream = torch.cuda.Stream(device=dev)
+    distribute_ms = 0.0
     if args.shard == "views":
-        # input planes live in a torch tensor so that RCCL (torch.distributed "nccl") can broadcast into them
-        grid = torch.empty((n_images, HEIGHT, WIDTH, 4), dtype=torch.uint8, device=dev)
+        # input planes live in a torch tensor so that RCCL (torch.distributed "nccl") can move them; padded so that it splits into
+        # `world` equal parts for the all-gather
+        plane = HEIGHT * WIDTH * 4
+        per_rank = -(-n_images // world)
+        flat = torch.empty((per_rank * world * plane,), dtype=torch.uint8, device=dev)
+        grid = flat[: n_images * plane].view(n_images, HEIGHT, WIDTH, 4)
         ctx.attach_grid(grid.data_ptr(), grid.numel())
         ctx.set_stream(stream.cuda_stream)
-        if rank == 0:
-            ctx.fill_synthetic(SEED)
-            ctx.sync()
-        L.broadcast_grid(grid, src=0)    # the one collective of the job: 531 MB over xGMI (RCCL), outside the timed region
+        g0, g1 = min(rank * per_rank, n_images), min((rank + 1) * per_rank, n_images)
+        if args.distribute == "broadcast":
+            if rank == 0:
+                ctx.fill_synthetic(SEED)
+        else:
+            ctx.fill_synthetic(SEED, g0, g1)             # this rank's slice only (real data: this rank's share of the uploads)
+        ctx.sync()
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            t_d = time.perf_counter()
+            if args.distribute == "broadcast":
+                L.broadcast_grid(grid, src=0)            # the one collective of the job over xGMI (RCCL), outside the timed region
+            else:
+                L.allgather_grid(flat, rank, world)      # in place: every rank contributes its 1/G, every link carries 1/G
+            torch.cuda.synchronize()
+            dist.barrier()
+            distribute_ms = (time.perf_counter() - t_d) * 1e3
         ctx.grid_modified()              # the attached planes were written by the collective, not through the ABI
         # host parameters for the whole trajectory; each rank keeps its own rows of the weight matrix
-        total_views = VIEWS_PER_GPU * world
-        hp, v0, v1 = L.rank_params(COLS, ROWS, WIDTH, HEIGHT, TRAJECTORY, FOCUS, 0.0, EFFECT, ASPECT, total_views, world, rank)
-        assert v1 - v0 == VIEWS_PER_GPU
+        hp, v0, v1 = L.rank_params(COLS, ROWS, WIDTH, HEIGHT, cfg["traj"], cfg["focus"], 0.0, cfg["effect"], cfg["aspect"], total_views, world, rank)
+        assert v1 - v0 == views_per_gpu
         in_rows_n = out_rows_n = HEIGHT
     else:
-        # one 64-view render split into row bands: no collective at all with synthetic data (every rank generates the rows it
+        # one render split into row bands: no collective at all with synthetic data (every rank generates the rows it
         # holds; real data would be scattered band + halo per rank)
-        total_views = VIEWS_PER_GPU
-        hp = L.build_params(COLS, ROWS, WIDTH, HEIGHT, TRAJECTORY, FOCUS, 0.0, EFFECT, ASPECT, total_views)
+        hp = L.build_params(COLS, ROWS, WIDTH, HEIGHT, cfg["traj"], cfg["focus"], 0.0, cfg["effect"], cfg["aspect"], total_views)
         band = L.row_band(HEIGHT, world, rank)
         held = L.input_rows(band, hp.focused_offsets, HEIGHT)
         ctx.set_row_window(band[0], band[1], held[0], held[1])
@@ -141,9 +311,14 @@ def main() -> int:
         ctx.sync()
         ctx.grid_modified()              # attached planes: announce that they are final
     ctx.set_params(hp)
-    views = torch.empty((VIEWS_PER_GPU, out_rows_n, WIDTH, 4), dtype=torch.uint8, device=dev)
+    out_bpp = 4 if args.layout == "rgba" else 3
+    views = torch.empty((views_per_gpu * out_rows_n * WIDTH * out_bpp,), dtype=torch.uint8, device=dev)
+    if args.layout != "rgba":
+        ctx.set_output_layout(args.layout)
     ctx.attach_views(views.data_ptr(), views.numel())
     ctx.set_variant(args.method, args.variant)
+    ctx.prepare(args.method)             # the derived planar input copy is built (and timed) here, not in the first launch
+    mem = ctx.memory_info()
 
     def barrier():
         if world > 1:
@@ -167,71 +342,92 @@ def main() -> int:
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_name = ctx.last_kernel_name()
 
     t = torch.tensor([elapsed, kernel_ms / 1e3], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max, kernel_s_max = float(t[0]), float(t[1])
 
-    # cheap sanity check that the timed launches rendered something: alpha must be 255 everywhere, RGB not constant
-    sample = views[0, out_rows_n // 2, :64].cpu().numpy()
+    # cheap sanity check that the timed launches rendered something: alpha 255 everywhere, RGB not constant
+    sample = ctx.download_view(0)[ctx.out_rows[0] + out_rows_n // 2, :64]
     assert (sample[:, 3] == 255).all() and sample[:, :3].std() > 0, "render produced no image"
 
     if rank == 0:
         value = total_views * args.steps / elapsed_max
         # bytes per launch on this GPU: rows held of every input plane + rows rendered of every view
-        b_alg = 4.0 * WIDTH * (in_rows_n * n_images + out_rows_n * VIEWS_PER_GPU)
+        balg = b_alg(WIDTH, in_rows_n, n_images, out_rows_n, views_per_gpu)
+        reads_planar = kernel_name.startswith("blend_planar") or kernel_name.startswith("blend_p3")
+        b_moved = 1.0 * WIDTH * ((3 if reads_planar else 4) * in_rows_n * n_images + out_bpp * out_rows_n * views_per_gpu)
         t_launch = kernel_s_max / args.steps
-        achieved = b_alg / t_launch / 1e9
+        achieved = balg / t_launch / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")           # PMC-derived HBM bytes per launch, if measured
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.config == 2 and args.shard == "views":
             try:
-                traffic = json.load(open(tpath)).get(f"{args.method}/{args.variant}", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(f"{args.method}/{args.variant}/{args.layout}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        f_alg = 6.0 * n_images * VIEWS_PER_GPU * WIDTH * out_rows_n   # 3 channels × (multiply + add)
+        f_alg = 6.0 * n_images * views_per_gpu * WIDTH * out_rows_n   # 3 channels × (multiply + add)
+        how = {"broadcast": "grid broadcast once", "allgather": "grid all-gathered once from 1/G per rank"}[args.distribute]
         line = {
-            "metric": "novel views/sec + Gpix/sec, 8x8 LF @1080p TEN_WM" if args.method == "TEN_WM"
-                      else "novel views/sec + Gpix/sec, 8x8 LF @1080p STD",
+            "metric": f"novel views/sec + Gpix/sec, {COLS}x{ROWS} LF @{'1080p' if HEIGHT == 1080 else '4K'} {args.method}",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak" if args.shard == "views" else "strong",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f16" if args.method == "TEN_WM" else "f32", "data": "synthetic",
-            "config": {"workload": f"{COLS}x{ROWS} LF @{WIDTH}x{HEIGHT}, {VIEWS_PER_GPU}-view -t trajectory per GPU, "
-                                   f"-m {args.method}, -f {FOCUS} -a {ASPECT} -s {EFFECT:g}",
-                       "views_per_gpu": VIEWS_PER_GPU, "images": n_images, "variant": args.variant,
-                       "inputs": ("resident in HBM before the timed region: RGBA planes + the planar alpha-free copy the TEN_WM kernel "
-                                  "reads (derived once per change of the inputs by planar_build, ~0.7 ms, DESIGN.md 4.1)"
-                                  if args.method == "TEN_WM" and args.variant in ("auto", "planar_m2_nt", "planar_m2", "planar_ring2_nt")
-                                  else "resident in HBM before the timed region: RGBA planes"),
-                       "parallelism": (f"views sharded over {world} GPU(s), grid broadcast once ({'gloo rehearsal' if rehearse else 'RCCL'})"
+            "config": {"workload": f"{COLS}x{ROWS} LF @{WIDTH}x{HEIGHT}, {views_per_gpu}-view -t trajectory per GPU"
+                                   + (f" ({total_views} views in all)" if world > 1 else "")
+                                   + f", -m {args.method}, -f {cfg['focus']} -a {cfg['aspect']} -s {cfg['effect']:g}",
+                       "baseline_config": args.config,
+                       "views_per_gpu": views_per_gpu, "images": n_images, "variant": args.variant, "kernel": kernel_name,
+                       "view_layout": ("RGBA planes (the reference's)" if args.layout == "rgba" else
+                                       "alpha-free byte planes [view][R,G,B][H][W] (opt-in, lfi_set_output_layout; alpha = 255 is re-created "
+                                       "on download)"),
+                       "inputs": ("resident in HBM before the timed region: RGBA planes + the derived planar alpha-free copy the kernel "
+                                  "reads (built once per change of the inputs, outside every render: DESIGN.md 4.1)"
+                                  if reads_planar else "resident in HBM before the timed region: RGBA planes"),
+                       "derived_copy_bytes": mem.derived_bytes, "derived_copy_build_ms": mem.derived_build_ms,
+                       "grid_bytes": mem.grid_bytes,
+                       "parallelism": (f"views sharded over {world} GPU(s), {how} ({'gloo rehearsal' if rehearse else 'RCCL'})"
                                        if args.shard == "views" else
                                        f"rows sharded over {world} GPU(s): {out_rows_n} output rows from {in_rows_n} input rows on rank 0, "
-                                       "no collective")},
+                                       "no collective"),
+                       "distribute_ms": distribute_ms,
+                       "multi_gpu_hardware_runs": ("this line" if world > 1 and not rehearse else
+                                                   "none by the builder: gpurun offers one GPU; N > 1 is covered by gloo tests and a one-GPU "
+                                                   "rehearsal, the driver's SCALE run is the first RCCL execution")},
             "gpix_per_s": value * WIDTH * HEIGHT / 1e9,
             "prewarm_ms": args.prewarm_ms,
             "kernel_ms_per_launch": t_launch * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": b_alg, "frac_of_measured_copy_6290": achieved / 6290.0,
-                         "mfma_frac_of_2500_tflops": f_alg / t_launch / 2.5e15},
+                         "traffic_source": "profiled constant: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/traffic.json "
+                                           "(not measured in this run)" if traffic else None,
+                         "algorithmic_bytes_per_launch": balg,
+                         "layout_bytes_per_launch": b_moved, "frac_moved": b_moved / t_launch / 1e9 / HBM_PEAK_GBS,
+                         "frac_of_measured_copy_6290": achieved / 6290.0,
+                         "mfma_frac_of_2500_tflops": f_alg / t_launch / 1e12 / F16_MFMA_PEAK_TFLOPS},
         }
         if args.method == "STD" and args.variant not in ("auto", "filtered_m2_nt"):
-            # the exact-fp32 MFMA kernels are bound by the fp32 matrix pipe (the default STD kernel computes on the
-            # fp16 matrix pipe and recomputes the sums near x.5 with the fmaf chain: HBM-bound like TEN_WM): F_alg = 6·N·V·W·H flops per launch against
-            # the dense fp32 matrix peak (157.3 TFLOP/s: 256 CUs × 4 SIMDs × 64 flop/cycle × 2.4 GHz)
+            # the exact-fp32 kernels are bound by the fp32 FMA lanes (the default STD kernel computes on the fp16
+            # matrix pipe and recomputes the sums near x.5 with the fmaf chain: HBM-bound like TEN_WM)
             tflops = f_alg / t_launch / 1e12
-            line["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": tflops / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+            line["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": tflops / FP32_PEAK_TFLOPS, "traffic": traffic,
                                 "algorithmic_flops_per_launch": f_alg, "hbm_frac_of_8000_gbs": achieved / HBM_PEAK_GBS}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 2:
             threads = min(os.cpu_count() or 1, 16)
-            line["cpu_baseline"] = cpu_baseline(hp, threads)
-        print(json.dumps(line), flush=True)
+            line["cpu_baseline"] = cpu_baseline(cfg, hp, threads)
 
     ctx.close()
+    del views, grid
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if world == 1 and not args.no_also and args.config == 2 and args.shard == "views":
+            line["also"] = also_table(L, device_index, args.also_iters, args.layout)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0

@@ -51,9 +51,10 @@ enum {
 
 /* lfi_params.flags */
 enum {
-    /* all-focus renders read focus map 1 (filtered) for both methods by default; with this flag TEN_WM reads the
-     * unfiltered map 0 as the reference does (src/kernels.cu:430 vs :326; SURVEY.md defect D7) */
-    LFI_FLAG_REFERENCE_MAP_QUIRK = 1u,
+    /* By default all-focus renders read the focus maps the reference's kernels read: Standard::process the filtered map 1
+     * (src/kernels.cu:326), Tensors::process the unfiltered map 0 (src/kernels.cu:430) — an inconsistency of the reference
+     * (SURVEY.md defect D7) that is reproduced so that outputs match it.  With this flag both methods read map 1. */
+    LFI_FLAG_UNIFIED_FOCUS_MAP = 1u,
     /* TEN_WM debug numerics: re-round the accumulator to fp16 after every 16-image batch, which reproduces the
      * reference's half-accumulator WMMA model (oracle model M16) instead of one final rounding */
     LFI_FLAG_TEN_ROUND_PER_BATCH = 2u
@@ -135,11 +136,30 @@ int lfi_grid_modified(lfi_ctx *ctx);
 /* fill the input planes on the device with the synthetic light field of SURVEY.md §8(d):
  * byte = hash32(seed, g, y, x, c) >> 24, alpha 255 (identical to oracle lfo_fill_synthetic) */
 int lfi_fill_synthetic(lfi_ctx *ctx, uint32_t seed);
+/* the same for images [g0, g1) only — a rank of an all-gather distribution generates (or uploads) just its own slice */
+int lfi_fill_synthetic_images(lfi_ctx *ctx, uint32_t seed, int g0, int g1);
 
 /* ---- parameters: replaces loadGPUOffsets / loadGPUWeights / selectFocusMapViews / loadGPUConstants
  *      (src/interpolator.cu:139-154, 194-246) ------------------------------------------------------------------ */
 int lfi_set_params(lfi_ctx *ctx, const lfi_params *params);
-/* caller-owned device memory for the V output planes ([V][H][W][4] u8); call after lfi_set_params */
+/* Device layout of the rendered views.  LFI_LAYOUT_RGBA (default): [V][rows][W] RGBA8 dwords — the linear image of the
+ * reference's 64 output surfaces.  LFI_LAYOUT_PLANAR_RGB (opt-in): alpha-free byte planes [V][3: R,G,B][rows][pitch] — the alpha
+ * the reference's kernels write is the constant 255 (uchar4{…, 255}, src/kernels.cu:393, :309), a quarter of the bytes a render
+ * writes; in this layout it is not stored and lfi_download_view / _quilt re-create it, so host-side results are byte-identical.
+ * TEN_WM fixed-focus renders write the planes directly (csrc/hip/blend_p3.hpp); every other render goes through the RGBA kernels
+ * and is converted.  Call after lfi_set_grid; frees the context's views (an attached buffer is dropped: attach again with the new
+ * size); rows = the rows this context renders (all, or its row window). */
+enum { LFI_LAYOUT_RGBA = 0, LFI_LAYOUT_PLANAR_RGB = 1 };
+int lfi_set_output_layout(lfi_ctx *ctx, int layout);
+typedef struct lfi_view_layout_info {
+    int32_t layout;            /* LFI_LAYOUT_* */
+    int32_t rows;              /* rows per plane */
+    size_t row_pitch_bytes;    /* RGBA: W*4; planar: W rounded up to 16 */
+    size_t plane_stride_bytes; /* planar: bytes from a view's R plane to its G plane; RGBA: 0 */
+    size_t view_stride_bytes;  /* bytes from view v to view v+1 */
+} lfi_view_layout_info;
+int lfi_view_layout(lfi_ctx *ctx, lfi_view_layout_info *out);
+/* caller-owned device memory for the V views in the current layout (V * view_stride_bytes); call after lfi_set_params */
 int lfi_attach_views(lfi_ctx *ctx, void *device_ptr, size_t bytes);
 int lfi_views_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes);
 
@@ -150,6 +170,24 @@ int lfi_focus_map(lfi_ctx *ctx);
 /* One launch of Tensors::process / Standard::process (src/interpolator.cu:274-288) for views [v0, v1).
  * all_focus != 0 selects the <true> instantiations (per-pixel focus from the focus map). */
 int lfi_render(lfi_ctx *ctx, int method, int all_focus, int v0, int v1);
+/* Do now what the first such lfi_render would otherwise do before its launch: (re)build the derived, alpha-free planar copy of
+ * the inputs if that launch would read it, and time it.  Optional; synchronous.  No counterpart in the
+ * reference (its surfaces are read as uploaded). */
+int lfi_prepare(lfi_ctx *ctx, int method, int all_focus, int v0, int v1);
+/* device memory this context holds, and what the derived copy cost to build (ms, as measured by the last lfi_prepare that
+ * built it; 0 otherwise) — the capacity side of the planar-copy trade, reported by bench.py */
+typedef struct lfi_memory {
+    size_t grid_bytes;      /* input planes (RGBA) */
+    size_t derived_bytes;   /* planar copy of the inputs: 12 bytes per pixel and image (+ padding) */
+    size_t views_bytes;     /* output planes */
+    size_t maps_bytes;      /* focus maps */
+    size_t workspace_bytes; /* focus-map workspace */
+    float derived_build_ms;
+} lfi_memory;
+int lfi_memory_info(lfi_ctx *ctx, lfi_memory *out);
+/* name of the blend kernel the last lfi_render / lfi_benchmark of this context launched ("" before the first) — lets the
+ * measurement harness label its numbers with what actually ran (dispatch depends on shape, weights and mode) */
+const char *lfi_last_kernel_name(const lfi_ctx *ctx);
 /* The reference's benchmark loop (src/interpolator.cu:270-295) with warm-up launches excluded. Synchronous. */
 int lfi_benchmark(lfi_ctx *ctx, int method, int all_focus, int v0, int v1, int warmup, int runs,
                   lfi_bench_stats *out_stats);
@@ -173,7 +211,9 @@ int lfi_free_pinned(void *ptr);
 
 /* ---- plumbing ------------------------------------------------------------------------------------------------- */
 
-/* enqueue on a caller-owned hipStream_t (NULL restores the context's own stream) */
+/* enqueue on a caller-owned hipStream_t (NULL restores the context's own stream).  Work already enqueued on the stream in use so
+ * far (fills, uploads, the derived input copy, focus maps, renders) is ordered before everything enqueued on the new one by an
+ * event — no host synchronisation; the stream switched away from must still exist at the time of the call. */
 int lfi_set_stream(lfi_ctx *ctx, void *hip_stream);
 /* choose a kernel variant by name for a method — or for the focus-map estimate with LFI_KERNEL_FOCUS_ESTIMATE —
  * ("auto" = default); used by the benchmark harness and the parity tests */
@@ -192,6 +232,10 @@ int lfi_download_prequant(lfi_ctx *ctx, int method, int all_focus, int v, float 
 /* hardware probe: C[32x32] = A[32x16] (fp16 bits) · B[16x32] (fp16 bits) with one v_mfma_f32_32x32x16_f16,
  * row-major in/out — checks the fragment lane maps and fp16-subnormal handling with exact data */
 int lfi_debug_mfma_f16(lfi_ctx *ctx, const uint16_t *a_32x16, const uint16_t *b_16x32, float *c_32x32);
+/* hardware probe: C[32x32] = A[32xk] · B[kx32] accumulated as the kernels accumulate — shape 0: k/16 chained
+ * v_mfma_f32_32x32x16_f16, shape 1: k/32 chained v_mfma_f32_16x16x32_f16 per quadrant; k a multiple of 32, ≤ 256.  Measures the
+ * matrix pipe's fp32 accumulation error, which the default STD kernel's rounding band assumes a bound for. */
+int lfi_debug_mfma_f16_chain(lfi_ctx *ctx, int shape, int k, const uint16_t *a_32xk, const uint16_t *b_kx32, float *c_32x32);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ from .build import HIP_LIB
 
 LFI_METHOD_STD = 0
 LFI_METHOD_TEN_WM = 1
-LFI_FLAG_REFERENCE_MAP_QUIRK = 1
+LFI_FLAG_UNIFIED_FOCUS_MAP = 1
 LFI_FLAG_TEN_ROUND_PER_BATCH = 2
 LFI_KERNEL_FOCUS_ESTIMATE = 2
 METHODS = {"STD": LFI_METHOD_STD, "TEN_WM": LFI_METHOD_TEN_WM, "FOCUS": LFI_KERNEL_FOCUS_ESTIMATE}
@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
     "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
-    "lfi_grid_modified",
+    "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_debug_mfma_f16_chain",
 ]
 
 
@@ -40,6 +40,21 @@ class _Params(C.Structure):
 class BenchStats(C.Structure):
     _fields_ = [("runs", C.c_int32), ("mean_ms", C.c_float), ("median_ms", C.c_float), ("min_ms", C.c_float),
                 ("max_ms", C.c_float), ("back_to_back_ms", C.c_float)]
+
+
+LFI_LAYOUT_RGBA = 0
+LFI_LAYOUT_PLANAR_RGB = 1
+LAYOUTS = {"rgba": LFI_LAYOUT_RGBA, "planar": LFI_LAYOUT_PLANAR_RGB}
+
+
+class ViewLayout(C.Structure):
+    _fields_ = [("layout", C.c_int32), ("rows", C.c_int32), ("row_pitch_bytes", C.c_size_t), ("plane_stride_bytes", C.c_size_t),
+                ("view_stride_bytes", C.c_size_t)]
+
+
+class MemoryInfo(C.Structure):
+    _fields_ = [("grid_bytes", C.c_size_t), ("derived_bytes", C.c_size_t), ("views_bytes", C.c_size_t), ("maps_bytes", C.c_size_t),
+                ("workspace_bytes", C.c_size_t), ("derived_build_ms", C.c_float)]
 
 
 _lib = None
@@ -98,6 +113,13 @@ def load_hip_library() -> C.CDLL:
         "lfi_download_coords": (i, [vp, i, i, i, vp]),
         "lfi_download_prequant": (i, [vp, i, i, i, vp]),
         "lfi_debug_mfma_f16": (i, [vp, vp, vp, vp]),
+        "lfi_prepare": (i, [vp, i, i, i, i]),
+        "lfi_debug_mfma_f16_chain": (i, [vp, i, i, vp, vp, vp]),
+        "lfi_set_output_layout": (i, [vp, i]),
+        "lfi_view_layout": (i, [vp, C.POINTER(ViewLayout)]),
+        "lfi_fill_synthetic_images": (i, [vp, C.c_uint32, i, i]),
+        "lfi_memory_info": (i, [vp, C.POINTER(MemoryInfo)]),
+        "lfi_last_kernel_name": (C.c_char_p, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not export what lfi.h declares
@@ -198,8 +220,11 @@ class Context:
         """The input planes were written behind the library's back (attached buffer, raw device pointer)."""
         self._check(self._lib.lfi_grid_modified(self._h))
 
-    def fill_synthetic(self, seed: int) -> None:
-        self._check(self._lib.lfi_fill_synthetic(self._h, seed))
+    def fill_synthetic(self, seed: int, g0: int | None = None, g1: int | None = None) -> None:
+        if g0 is None and g1 is None:
+            self._check(self._lib.lfi_fill_synthetic(self._h, seed))
+        else:
+            self._check(self._lib.lfi_fill_synthetic_images(self._h, seed, g0 or 0, self.n_images if g1 is None else g1))
 
     # -- parameters --------------------------------------------------------------------------------------------
     def set_params(self, hp, flags: int = 0) -> None:
@@ -224,6 +249,15 @@ class Context:
         self._check(self._lib.lfi_set_params(self._h, C.byref(p)))
         self.views = w.shape[0]
 
+    def set_output_layout(self, layout) -> None:
+        """'rgba' (the reference's planes) or 'planar' (alpha-free byte planes; downloads re-create alpha = 255)."""
+        self._check(self._lib.lfi_set_output_layout(self._h, LAYOUTS[layout] if isinstance(layout, str) else layout))
+
+    def view_layout(self) -> ViewLayout:
+        vl = ViewLayout()
+        self._check(self._lib.lfi_view_layout(self._h, C.byref(vl)))
+        return vl
+
     def attach_views(self, device_ptr: int, nbytes: int) -> None:
         self._check(self._lib.lfi_attach_views(self._h, C.c_void_p(device_ptr), nbytes))
 
@@ -239,6 +273,18 @@ class Context:
     def render(self, method, all_focus: bool = False, v0: int = 0, v1: int | None = None) -> None:
         m = METHODS[method] if isinstance(method, str) else method
         self._check(self._lib.lfi_render(self._h, m, int(all_focus), v0, self.views if v1 is None else v1))
+
+    def prepare(self, method, all_focus: bool = False, v0: int = 0, v1: int | None = None) -> None:
+        m = METHODS[method] if isinstance(method, str) else method
+        self._check(self._lib.lfi_prepare(self._h, m, int(all_focus), v0, self.views if v1 is None else v1))
+
+    def memory_info(self) -> MemoryInfo:
+        mi = MemoryInfo()
+        self._check(self._lib.lfi_memory_info(self._h, C.byref(mi)))
+        return mi
+
+    def last_kernel_name(self) -> str:
+        return self._lib.lfi_last_kernel_name(self._h).decode()
 
     def benchmark(self, method, all_focus=False, v0=0, v1=None, warmup=3, runs=20) -> BenchStats:
         m = METHODS[method] if isinstance(method, str) else method
@@ -322,6 +368,16 @@ class Context:
         out = np.empty((self.height, self.width, 3), dtype=np.float32)
         self._check(self._lib.lfi_download_prequant(self._h, m, int(all_focus), v, _ptr(out)))
         return out
+
+    def debug_mfma_f16_chain(self, a_bits: np.ndarray, b_bits: np.ndarray, shape: int = 0) -> np.ndarray:
+        """C[32][32] = A[32][K] · B[K][32] (fp16 bit patterns) through K/16 (shape 0) or K/32 (shape 1) chained MFMAs."""
+        a = np.ascontiguousarray(a_bits, dtype=np.uint16)
+        b = np.ascontiguousarray(b_bits, dtype=np.uint16)
+        k = a.shape[1]
+        assert a.shape == (32, k) and b.shape == (k, 32)
+        c = np.empty((32, 32), dtype=np.float32)
+        self._check(self._lib.lfi_debug_mfma_f16_chain(self._h, shape, k, _ptr(a), _ptr(b), _ptr(c)))
+        return c
 
     def debug_mfma_f16(self, a_bits: np.ndarray, b_bits: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(a_bits, dtype=np.uint16)

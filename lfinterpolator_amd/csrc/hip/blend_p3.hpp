@@ -1,0 +1,382 @@
+// blend_p3.hpp — TEN_WM with three bytes per pixel on BOTH sides of the kernel: the planar, alpha-free copy of the inputs
+// (blend_planar.hpp) is read, and the views are written as alpha-free byte planes [view][R,G,B][rows][pitch].
+//
+// Why: the blend is HBM-bound and the memory system gives this access pattern ≈4.8–5 TB/s whatever the kernel does
+// (tools/ablate_out.hip: the same gather with no arithmetic, 929 MB moved: 188–197 µs with RGBA views, 796 MB: 160–165 µs with
+// planar views, on one box) — bytes are the lever left.  A quarter of the bytes blend_planar WRITES is the constant alpha = 255
+// (reference src/kernels.cu:393 `uchar4{…, 255}`).  This kernel does not write it: views are stored as byte planes when the
+// caller opts in (lfi_set_output_layout, include/lfi.h) and the alpha byte is re-created when a view is downloaded.
+//
+// Byte planes want a lane to own CONSECUTIVE pixels of one view and channel (a dword or more per store, 128 B per plane row and
+// store instruction).  blend_planar's wave = 32 pixels × 64 views on v_mfma_f32_32x32x16_f16 gives a lane one pixel; here a
+// wave = 128 pixels × 16 views on v_mfma_f32_16x16x32_f16:
+//      A = weights  (lane l: view l&15,  images 8(l>>4)+j, j < 8)        — 16 views of this wave, held in registers for the launch
+//      B = pixels   (lane l: column l&15, images 8(l>>4)+j)             — eight MFMAs "blk" = 0..7 per k-step and channel;
+//                                                                          column n of block blk IS pixel 8n + blk of the tile
+//      D            (lane l: column l&15, views 4(l>>4)+i, i < 4)
+// so lane (n, kg) ends up with pixels 8n … 8n+7 of views 4kg+i: one 8-byte store per (i, channel), 16 lanes = 128 B of one plane
+// row, four views per store instruction.  The column ↔ pixel map costs nothing: one ds_read_b64 at [channel][image][8n] returns
+// the lane's eight pixels of an image — one byte per block — and a v_perm_b32 per image pair and block builds the fp16-subnormal
+// operand (a pixel byte IS the subnormal's mantissa, blend_ten.hpp).  The four waves of a workgroup share the 128-pixel tile and
+// split the 64 views of a pass.
+//
+// Pipeline: persistent workgroups, a ring of three pixel buffers in LDS filled by LDS-DMA two units ahead (unit = tile × chunk of
+// 64 images), one barrier and one hand-counted s_waitcnt vmcnt per unit, as in blend_planar's one-chunk path — generalised to
+// any number of chunks (NCH ≤ 4, compile time: the weight fragments of all chunks stay in registers, ≤ 32 VGPRs).
+// LDS image of a buffer: [channel][octet of images][8 images × 128 B], octets padded so that the four octets a ds_read_b64
+// instruction touches (lanes kg = 0..3) fall into different banks.
+// Arithmetic and quantisation are blend_planar's (weights ×2^15, RN-even to fp16, saturate, truncate — src/kernels.cu:387-396):
+// identical bytes, tested against the oracle and against blend_planar.
+// Replaces Kernels::Tensors::process<false> (reference src/kernels.cu:398-461).
+#pragma once
+
+#include "blend_planar.hpp"
+
+namespace lfi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int P3_TPX = 128;               // pixels per tile
+constexpr int P3_KC = 64;                 // images per chunk
+constexpr int P3_CH_B = 8 * 1024 + 4 * 128; // one channel of a buffer: 8 octets of 1 KB, +128 B in front of every odd octet
+constexpr int P3_BUF_B = 3 * P3_CH_B;     // 26,112 B
+// byte offset of octet o (images 8o … 8o+7, 128 B each) inside a channel: a ds_read_b64 instruction is served in two groups of
+// 32 lanes over 64 banks of 4 B (MI355X_MICROARCH.md §LDS); lanes of kg = l>>4 read octet 4ks + kg, 128 contiguous bytes per
+// 16 lanes, so octets 4ks and 4ks+1 (and 4ks+2, 4ks+3) must start 128 B apart modulo 256
+__host__ __device__ constexpr int p3_octet_off(int o)
+{
+    return o * 1024 + 128 * ((o + 1) >> 1);
+}
+
+#define LFI_P3_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// planar views: plane (view, channel) at ((view·3 + channel)·rows)·pitch, pixel x of row y at y·pitch + x
+template <bool NT_STORE, int NCH>
+__global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int tiles_x, const int n_tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[3 * P3_BUF_B + LFI_MAX_IMAGES * 8];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int H = a.height;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr_t)lds)));
+    const size_t shift_stride = (size_t)a.in_rows * a.planar_pitch; // one byte plane of the planar inputs
+    int2 *off_table = reinterpret_cast<int2 *>(lds + 3 * P3_BUF_B);
+    for(int g = threadIdx.x; g < a.n_images; g += 256)
+    {
+        const lfi_int2 o = a.focused[g];
+        off_table[g] = make_int2(o.x, o.y);
+    }
+
+    // this wave's 16 views: all their weights, as MFMA A fragments (k-step s = images 32s … 32s+31)
+    const int vw = a.v0 + 16 * wave;
+    const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw, 16)); // ≤ 0: this wave only helps with the DMA
+    half8 wreg[2 * NCH];
+#pragma unroll
+    for(int s = 0; s < 2 * NCH; s++)
+    {
+        const int k = 32 * s + 8 * kg;
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if(k < a.k_pad) // rows are k_pad halves long (a multiple of 16): nothing is read across a row's end
+            w = *reinterpret_cast<const u32x4 *>(a.w16s + (size_t)(vw + n) * a.k_pad + k);
+        wreg[s] = __builtin_bit_cast(half8, w);
+    }
+    // the loads above are the only vector loads the compiler knows about: make it wait for them HERE, before any LDS-DMA is in
+    // flight, instead of with a vmcnt(0) in front of the first MFMA (which would also drain the pipeline's first three tiles)
+#pragma unroll
+    for(int s = 0; s < 2 * NCH; s++)
+        asm volatile("" : "+v"(wreg[s]));
+
+    const int G = gridDim.x;
+    const int t0 = int(xcd_contiguous(blockIdx.x, gridDim.x));
+    if(t0 >= n_tiles)
+        return;
+    __syncthreads(); // the offset table is complete
+
+    // pixel bytes of one unit: piece p (1 KB) = channel p / 8, octet p % 8 of the chunk; wave w moves pieces w, w + 4, …, i.e.
+    // octets w and w + 4 of every channel.  Per octet a lane needs its image's integer offsets and (channel 0) plane.
+    struct Pieces
+    {
+        int ox[2], oy[2];
+        size_t plane0[2];
+    };
+    auto lookup = [&](const int chunk) {
+        Pieces pc;
+#pragma unroll
+        for(int o2 = 0; o2 < 2; o2++)
+        {
+            const int octet = wave + 4 * o2;
+            const int g = min(P3_KC * chunk + 8 * octet + (lane >> 3), a.n_images - 1); // padded images (zero weights) re-read the last one
+            const int2 o = off_table[g];
+            pc.ox[o2] = o.x;
+            pc.oy[o2] = o.y;
+            pc.plane0[o2] = (size_t)g * 12 * shift_stride;
+        }
+        return pc;
+    };
+    // returns the number of DMA instructions issued by this wave (wave-uniform)
+    auto issue = [&](const int t, const int chunk, const int buf, const Pieces &pc) {
+        const int ty = t / tiles_x;
+        const int y = a.out_y0 + ty;
+        const int x0 = (t - ty * tiles_x) * P3_TPX;
+        const int kc = min(P3_KC, a.k_pad - P3_KC * chunk);
+        const uint32_t dst = lds_base + uint32_t(buf) * P3_BUF_B;
+        int count = 0;
+#pragma unroll
+        for(int o2 = 0; o2 < 2; o2++)
+        {
+            const int octet = wave + 4 * o2;
+            if(8 * octet >= kc)
+                continue; // wave-uniform: the chunk is shorter (its length is a multiple of 16)
+            // the run starts at pixel x0 + ox: dword aligned in shift copy (x0 + ox + padx) & 3; the padding exceeds every offset
+            const int sy = clampi(y + pc.oy[o2], 0, H - 1) - a.in_y0; // clamp in the full image, then index the held rows
+            const int start = x0 + pc.ox[o2] + a.planar_padx;
+            const int k = start & 3;
+            const uint8_t *src = a.planar + pc.plane0[o2] + ((size_t)k * a.in_rows + sy) * a.planar_pitch + (start - k) + 16 * (lane & 7);
+#pragma unroll
+            for(int ch = 0; ch < 3; ch++)
+                dma16(src + (size_t)ch * 4 * shift_stride, dst + uint32_t(ch * P3_CH_B + p3_octet_off(octet)));
+            count += 3;
+        }
+        return count;
+    };
+
+    f32x4 acc[8][3]; // [block = pixel 8n + blk][channel]: views 4kg + i
+#pragma unroll
+    for(int b = 0; b < 8; b++)
+#pragma unroll
+        for(int ch = 0; ch < 3; ch++)
+            acc[b][ch] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // k-loop of one unit from buffer `buf`: wk = the chunk's two weight fragments
+    const uint32_t lane_px = uint32_t(1024 * kg + 128 * ((kg + 1) >> 1) + 8 * n); // p3_octet_off(kg) + this lane's 8 pixels
+    auto compute = [&](const half8 (&wk)[2], const int buf, const int kc) {
+        const uint8_t *pb = lds + buf * P3_BUF_B + lane_px;
+#pragma unroll
+        for(int ks = 0; ks < 2; ks++)
+        {
+            if(32 * ks >= kc) // wave-uniform
+                continue;
+#pragma unroll
+            for(int ch = 0; ch < 3; ch++)
+            {
+                u32x2 d[8];
+#pragma unroll
+                for(int j = 0; j < 8; j++)
+                    d[j] = *reinterpret_cast<const u32x2 *>(pb + ch * P3_CH_B + p3_octet_off(4 * ks) + 128 * j);
+#pragma unroll
+                for(int b = 0; b < 8; b++)
+                {
+                    u32x4 bf;
+#pragma unroll
+                    for(int q = 0; q < 4; q++)
+                    {
+                        const uint32_t lo = b < 4 ? d[2 * q].x : d[2 * q].y, hi = b < 4 ? d[2 * q + 1].x : d[2 * q + 1].y;
+                        // [15:0] = byte (b & 3) of image 2q, [31:16] = the same byte of image 2q + 1: two fp16 subnormals
+                        bf[q] = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | uint32_t(b & 3) | (uint32_t(4 + (b & 3)) << 16));
+                    }
+                    acc[b][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[ks], __builtin_bit_cast(half8, bf), acc[b][ch], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // epilogue of tile t: quantise (acc = S·2^-9), pack eight pixels per (view, channel), store; returns the number of store
+    // instructions issued (wave-uniform); clears acc
+    const uint32_t plane_b = uint32_t(a.out_rows) * uint32_t(a.views_pitch); // bytes of one byte plane (< 2^26·… checked on the host)
+    auto epilogue = [&](const int t) {
+        const int ty = t / tiles_x; // row inside the output window
+        const int x0 = (t - ty * tiles_x) * P3_TPX;
+        uint32_t hq[48]; // [(i·3 + channel)·4 + block pair]: two halves, 0x4000 | byte after the rounding-mode window
+#pragma unroll
+        for(int i = 0; i < 4; i++)
+#pragma unroll
+            for(int ch = 0; ch < 3; ch++)
+#pragma unroll
+                for(int p = 0; p < 4; p++)
+                {
+                    const float2_t f = {acc[2 * p][ch][i], acc[2 * p + 1][ch][i]};
+                    hq[(i * 3 + ch) * 4 + p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2_t)); // v_cvt_pk_f16_f32: RN-even
+                }
+        const uint32_t k255 = 0x37f837f8u; // 255·2^-9 twice
+        const uint32_t two = 0x40004000u;  // 2.0 twice
+#pragma unroll
+        for(int half = 0; half < 2; half++)
+        {
+#define h(k) hq[24 * half + (k)]
+            // saturate at 255, then + 2.0 under round-toward-zero leaves floor(S) in the low mantissa byte (blend_ten_lds.hpp);
+            // everything that depends on the fp16 rounding mode sits in ONE asm statement together with the two mode writes
+            asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3\n\ts_nop 1\n\t" LFI_QA(0) LFI_QA(1) LFI_QA(2) LFI_QA(3) LFI_QA(4)
+                             LFI_QA(5) LFI_QA(6) LFI_QA(7) LFI_QA(8) LFI_QA(9) LFI_QA(10) LFI_QA(11) LFI_QA(12) LFI_QA(13) LFI_QA(14)
+                                 LFI_QA(15) LFI_QA(16) LFI_QA(17) LFI_QA(18) LFI_QA(19) LFI_QA(20) LFI_QA(21) LFI_QA(22) LFI_QA(23)
+                         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0\n\ts_nop 1"
+                         : "+v"(h(0)), "+v"(h(1)), "+v"(h(2)), "+v"(h(3)), "+v"(h(4)), "+v"(h(5)), "+v"(h(6)), "+v"(h(7)), "+v"(h(8)),
+                           "+v"(h(9)), "+v"(h(10)), "+v"(h(11)), "+v"(h(12)), "+v"(h(13)), "+v"(h(14)), "+v"(h(15)), "+v"(h(16)),
+                           "+v"(h(17)), "+v"(h(18)), "+v"(h(19)), "+v"(h(20)), "+v"(h(21)), "+v"(h(22)), "+v"(h(23))
+                         : "s"(k255), "s"(two));
+#undef h
+        }
+        // wave-uniform 64-bit base per store + one 32-bit per-lane byte offset (12 planes < 4 GB)
+        uint8_t *ubase = a.views + ((size_t)vw * 3 * a.out_rows + ty) * a.views_pitch + x0;
+        const uint32_t lane_off = uint32_t(12 * kg) * plane_b + uint32_t(8 * n);
+        const bool x_ok = x0 + 8 * n < a.views_pitch; // the pitch is a multiple of 16 ≥ W: a whole 8-byte store stays inside the row
+        int n_st = 0;
+#pragma unroll
+        for(int i = 0; i < 4; i++)
+        {
+            if(i >= nvalid) // wave-uniform; otherwise lane (n = 0, kg = 0) is active and every store below is issued
+                continue;
+#pragma unroll
+            for(int ch = 0; ch < 3; ch++)
+            {
+                const uint32_t *q = &hq[(i * 3 + ch) * 4];
+                const u32x2 px8 = {__builtin_amdgcn_perm(q[1], q[0], 0x06040200u),  // pixels 8n … 8n+3
+                                   __builtin_amdgcn_perm(q[3], q[2], 0x06040200u)}; // pixels 8n+4 … 8n+7
+                u32x2 *out = reinterpret_cast<u32x2 *>(ubase + (size_t)(3 * i + ch) * plane_b + lane_off);
+                n_st++;
+                if(x_ok && 4 * kg + i < nvalid)
+                {
+                    if constexpr(NT_STORE)
+                        __builtin_nontemporal_store(px8, out);
+                    else
+                        *out = px8;
+                }
+            }
+        }
+#pragma unroll
+        for(int b = 0; b < 8; b++)
+#pragma unroll
+            for(int ch = 0; ch < 3; ch++)
+                acc[b][ch] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        return n_st;
+    };
+
+    // ---- the unit sequence of this workgroup: tiles t0, t0 + G, …; chunks 0 … NCH−1 of each -------------------------------------
+    int it = t0, ic = 0; // issue cursor: the next unit to fetch
+    auto advance_issue = [&] {
+        if(++ic == NCH)
+        {
+            ic = 0;
+            it += G;
+        }
+    };
+    Pieces pc = lookup(0);
+    issue(it, ic, 0, pc);
+    advance_issue();
+    if constexpr(NCH > 1)
+        pc = lookup(ic);
+    bool have1 = it < n_tiles; // a unit after the current one exists (and is in flight)
+    int nd1 = 0;               // its DMA instructions
+    if(have1)
+    {
+        nd1 = issue(it, ic, 1, pc);
+        advance_issue();
+        if constexpr(NCH > 1)
+            pc = lookup(ic);
+    }
+    int ct = t0, cc = 0, buf = 0; // compute cursor
+    int st1 = 0, st2 = 0;         // store instructions of the previous unit's epilogue and of the one before
+    while(true)
+    {
+        // VMEM operations of this wave younger than the current unit's DMA: stores(u−2), DMA(u+1), stores(u−1) — they may stay in
+        // flight; vmcnt retires in order, so "at most that many outstanding" means the current unit's pieces have landed
+        const int allowed = st2 + (have1 ? nd1 : 0) + st1;
+        switch(min(allowed, 31) >> 2)
+        {
+            case 7: LFI_P3_WAIT(28); break;
+            case 6: LFI_P3_WAIT(24); break;
+            case 5: LFI_P3_WAIT(20); break;
+            case 4: LFI_P3_WAIT(16); break;
+            case 3: LFI_P3_WAIT(12); break;
+            case 2: LFI_P3_WAIT(8); break;
+            case 1: LFI_P3_WAIT(4); break;
+            default: LFI_P3_WAIT(0); break;
+        }
+        __builtin_amdgcn_s_barrier(); // everybody's pieces of this unit have landed; everybody is done with the previous unit's buffer
+        asm volatile("" ::: "memory");
+        const bool have2 = have1 && it < n_tiles;
+        int nd2 = 0;
+        if(have2)
+        {
+            nd2 = issue(it, ic, buf == 0 ? 2 : buf - 1, pc); // (buf + 2) % 3: the buffer the previous unit used
+            advance_issue();
+            if constexpr(NCH > 1)
+                pc = lookup(ic); // for the unit after that: off the critical path of the next barrier
+        }
+        const int kc = min(P3_KC, a.k_pad - P3_KC * cc);
+        if(nvalid > 0)
+        {
+            // the chunk's fragments by wave-uniform selects over compile-time register indices (a runtime index would put wreg
+            // into scratch, and scratch accesses would enter the vmcnt queue the waits above count)
+            half8 wk[2] = {wreg[0], wreg[1]};
+#pragma unroll
+            for(int c = 1; c < NCH; c++)
+                if(cc == c)
+                {
+                    wk[0] = wreg[2 * c];
+                    wk[1] = wreg[2 * c + 1];
+                }
+            compute(wk, buf, kc);
+        }
+        st2 = st1;
+        st1 = 0;
+        if(cc == NCH - 1 && nvalid > 0)
+            st1 = epilogue(ct);
+        if(!have1)
+            break;
+        if(++cc == NCH)
+        {
+            cc = 0;
+            ct += G;
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+        have1 = have2;
+        nd1 = nd2;
+    }
+}
+
+// ---- layout conversions for the planar view layout ------------------------------------------------------------------------------
+
+// RGBA planes [views][rows][W] dwords → byte planes [views][3][rows][pitch]: for renders that only the RGBA kernels serve
+// (STD, all-focus, debug modes) when the context's views are planar.  grid (ceil(pitch/4 / 256), rows, views)
+__global__ void __launch_bounds__(256) views_rgba_to_planar(const uint32_t *__restrict__ rgba, uint8_t *__restrict__ planar, const int W, const int rows,
+                                                            const int pitch)
+{
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if(x4 >= pitch)
+        return;
+    const int y = blockIdx.y, v = blockIdx.z;
+    const uint32_t *row = rgba + ((size_t)v * rows + y) * W;
+    uint32_t px[4];
+#pragma unroll
+    for(int i = 0; i < 4; i++)
+        px[i] = x4 + i < W ? row[x4 + i] : 0u;
+#pragma unroll
+    for(int ch = 0; ch < 3; ch++)
+    {
+        const uint32_t lo = __builtin_amdgcn_perm(px[1], px[0], 0x0c0c0400u + 0x0101u * uint32_t(ch)); // [p0.ch, p1.ch, 0, 0]
+        const uint32_t hi = __builtin_amdgcn_perm(px[3], px[2], 0x0c0c0400u + 0x0101u * uint32_t(ch));
+        *reinterpret_cast<uint32_t *>(planar + (((size_t)v * 3 + ch) * rows + y) * pitch + x4) = lo | (hi << 16);
+    }
+}
+
+// one view: byte planes → an RGBA plane with alpha 255 (uchar4{…, 255}, reference src/kernels.cu:393); grid (ceil(W/4 / 256), rows)
+__global__ void __launch_bounds__(256) view_planar_to_rgba(const uint8_t *__restrict__ planar_view, uint32_t *__restrict__ rgba, const int W, const int rows,
+                                                           const int pitch)
+{
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if(x4 >= W)
+        return;
+    const int y = blockIdx.y;
+    uint32_t c[3];
+#pragma unroll
+    for(int ch = 0; ch < 3; ch++)
+        c[ch] = *reinterpret_cast<const uint32_t *>(planar_view + ((size_t)ch * rows + y) * pitch + x4); // pitch is a multiple of 16
+#pragma unroll
+    for(int i = 0; i < 4; i++)
+        if(x4 + i < W)
+            rgba[(size_t)y * W + x4 + i] = ((c[0] >> (8 * i)) & 0xffu) | (((c[1] >> (8 * i)) & 0xffu) << 8) | (((c[2] >> (8 * i)) & 0xffu) << 16) | 0xff000000u;
+}
+
+} // namespace lfi

@@ -293,4 +293,61 @@ __global__ void __launch_bounds__(64) probe_mfma_f16(const uint16_t *__restrict_
         c[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = d[e];
 }
 
+// hardware probe used by lfi_debug_mfma_f16_chain: C[32][32] = A[32][K] · B[K][32] (row-major fp16 bit patterns, K a multiple of
+// 32) accumulated exactly as the kernels accumulate — SHAPE 0: K/16 chained v_mfma_f32_32x32x16_f16 (blend_planar, blend_persist),
+// SHAPE 1: K/32 chained v_mfma_f32_16x16x32_f16 per 16×16 quadrant (blend_p3); the accumulator of one instruction is the C operand
+// of the next.  Measures what the matrix pipe's fp32 accumulation does to sums whose addends differ by many binades.
+template <int SHAPE>
+__global__ void __launch_bounds__(64) probe_mfma_f16_chain(const uint16_t *__restrict__ a, const uint16_t *__restrict__ b, const int K,
+                                                          float *__restrict__ c)
+{
+    const int lane = threadIdx.x & 63;
+    if constexpr(SHAPE == 0)
+    {
+        const int r = lane & 31, h = lane >> 5;
+        f32x16 d;
+#pragma unroll
+        for(int e = 0; e < 16; e++)
+            d[e] = 0.0f;
+        for(int k0 = 0; k0 < K; k0 += 16)
+        {
+            half8 fa, fb;
+#pragma unroll
+            for(int j = 0; j < 8; j++)
+            {
+                fa[j] = __builtin_bit_cast(_Float16, a[r * K + k0 + 8 * h + j]);
+                fb[j] = __builtin_bit_cast(_Float16, b[(k0 + 8 * h + j) * 32 + r]);
+            }
+            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, d, 0, 0, 0);
+        }
+#pragma unroll
+        for(int e = 0; e < 16; e++)
+            c[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = d[e];
+    }
+    else
+    {
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        const int n = lane & 15, kg = lane >> 4;
+        for(int qi = 0; qi < 2; qi++)
+            for(int qj = 0; qj < 2; qj++)
+            {
+                f32x4_t d = {0.0f, 0.0f, 0.0f, 0.0f};
+                for(int k0 = 0; k0 < K; k0 += 32)
+                {
+                    half8 fa, fb;
+#pragma unroll
+                    for(int j = 0; j < 8; j++)
+                    {
+                        fa[j] = __builtin_bit_cast(_Float16, a[(16 * qi + n) * K + k0 + 8 * kg + j]);
+                        fb[j] = __builtin_bit_cast(_Float16, b[(k0 + 8 * kg + j) * 32 + 16 * qj + n]);
+                    }
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, d, 0, 0, 0);
+                }
+#pragma unroll
+                for(int i = 0; i < 4; i++)
+                    c[(16 * qi + 4 * kg + i) * 32 + 16 * qj + n] = d[i];
+            }
+    }
+}
+
 } // namespace lfi

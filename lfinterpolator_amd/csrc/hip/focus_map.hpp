@@ -499,15 +499,17 @@ __global__ void __launch_bounds__(256) dump_coords(const KernelArgs a, const int
 
 // synthetic light field of SURVEY.md §8(d), same hash as oracle lfo_hash32
 // rows_held rows per plane starting at global row y0 (the whole image: rows_held = H, y0 = 0)
-__global__ void __launch_bounds__(256) fill_synthetic(uint8_t *__restrict__ grid, const int n_images, const int W, const int H,
+__global__ void __launch_bounds__(256) fill_synthetic(uint8_t *__restrict__ grid, const int g_first, const int n_images, const int W, const int H,
                                                      const int y0, const uint32_t seed)
 {
+    // images g_first … g_first + n_images − 1 (grid points at plane 0)
+    grid += (size_t)g_first * W * H * 4;
     const size_t total = (size_t)n_images * W * H;
     for(size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
     {
         const uint32_t x = uint32_t(idx % W);
         const uint32_t y = uint32_t((idx / W) % H) + uint32_t(y0);
-        const uint32_t g = uint32_t(idx / ((size_t)W * H));
+        const uint32_t g = uint32_t(idx / ((size_t)W * H)) + uint32_t(g_first);
         uint32_t hy = mix32(mix32(seed + g * 0x9e3779b9u) + y * 0x85ebca6bu);
         uint32_t px = 0xff000000u;
 #pragma unroll

@@ -51,6 +51,7 @@ struct KernelArgs
     // pixel x of a row at byte x + planar_padx − shift, edges replicated into the padding
     const uint8_t *__restrict__ planar;
     int32_t planar_pitch, planar_padx;
+    int32_t views_pitch;                    // planar view layout (blend_p3.hpp): bytes per row of a byte plane [view][R,G,B][out_rows][views_pitch]
     float std_band;                         // blend_planar<STDF>: half-width of the band around x.5 inside which a sum is recomputed exactly
     int32_t map_index;                      // which focus map an all-focus render reads
     float focus, range;                     // inFocus, inRange

@@ -20,6 +20,7 @@
 #include "blend_ten_lds.hpp"
 #include "blend_ten_persist.hpp"
 #include "blend_planar.hpp"
+#include "blend_p3.hpp"
 #include "blend_wave.hpp"
 #include "focus_factored.hpp"
 #include "lfi_device.hpp"
@@ -52,6 +53,7 @@ struct lfi_ctx
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_order = nullptr; // orders the work of the stream a caller switches away from before the stream it switches to
     // side stream of the factored focus-map estimate (its small passes overlap the large ones), created on first use
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_pad = nullptr, ev_join = nullptr;
@@ -66,6 +68,11 @@ struct lfi_ctx
     uint8_t *views = nullptr;
     bool own_views = false;
     size_t views_bytes = 0;
+    int out_layout = LFI_LAYOUT_RGBA;  // device layout of the views (lfi_set_output_layout)
+    uint8_t *rgba_scratch = nullptr;   // planar layout: RGBA planes of all views for the kernels that only write RGBA (converted after the launch)
+    size_t rgba_scratch_bytes = 0;
+    uint8_t *dl_plane = nullptr;       // planar layout: one RGBA plane that downloads expand a view into
+    size_t dl_plane_bytes = 0;
     // parameter block
     bool have_params = false;
     int views_n = 0, k_pad = 0, v_pad = 0, n_focus_ids = 0;
@@ -92,6 +99,8 @@ struct lfi_ctx
     void *focus_ws = nullptr; // workspace of the factored focus-map estimate (plan, E, K), allocated on first use
     size_t focus_ws_bytes = 0;
     int ten_variant = 0, std_variant = 0, focus_variant = 0;
+    mutable const char *last_kernel = ""; // the blend kernel the last render launched (lfi_last_kernel_name)
+    float derived_build_ms = 0.0f;        // duration of the last planar_build (measured by lfi_prepare only)
     std::string err;
 };
 
@@ -131,9 +140,23 @@ size_t in_plane_bytes(const lfi_ctx *c)
     return (size_t)c->width * c->in_rows * 4;
 }
 
-size_t out_plane_bytes(const lfi_ctx *c)
+// planar view layout: bytes per row of a byte plane — a multiple of 16 so that every 8-byte store of blend_p3 is aligned and stays
+// inside its row whatever the width
+int view_pitch(const lfi_ctx *c)
+{
+    return (c->width + 15) / 16 * 16;
+}
+
+size_t rgba_out_plane_bytes(const lfi_ctx *c)
 {
     return (size_t)c->width * c->out_rows * 4;
+}
+
+size_t out_plane_bytes(const lfi_ctx *c) // one view as stored on the device
+{
+    if(c->out_layout == LFI_LAYOUT_PLANAR_RGB)
+        return (size_t)3 * c->out_rows * view_pitch(c);
+    return rgba_out_plane_bytes(c);
 }
 
 KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
@@ -169,16 +192,17 @@ KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
     a.std_band = float(c->n) * (0x1p-16f + 0x1p-15f) + 0x1p-11f;
     a.planar_pitch = c->planar_pitch;
     a.planar_padx = c->planar_padx;
+    a.views_pitch = view_pitch(c);
     a.fo_min_x = c->fo_min[0];
     a.fo_max_x = c->fo_max[0];
     a.fo_min_y = c->fo_min[1];
     a.fo_max_y = c->fo_max[1];
     a.radius_x = c->radius[0];
     a.radius_y = c->radius[1];
-    // the reference reads map 1 in Standard::process and map 0 in Tensors::process (src/kernels.cu:326 vs :430);
-    // both read the filtered map here unless the quirk flag asks for the reference's behaviour
+    // the reference reads map 1 in Standard::process and map 0 in Tensors::process (src/kernels.cu:326 vs :430): reproduced by
+    // default; LFI_FLAG_UNIFIED_FOCUS_MAP makes both read the filtered map
     a.map_index = 1;
-    if((c->flags & LFI_FLAG_REFERENCE_MAP_QUIRK) && all_focus_method == LFI_METHOD_TEN_WM)
+    if(all_focus_method == LFI_METHOD_TEN_WM && !(c->flags & LFI_FLAG_UNIFIED_FOCUS_MAP))
         a.map_index = 0;
     a.focus = c->focus;
     a.range = c->range;
@@ -192,6 +216,7 @@ dim3 pixel_grid(const lfi_ctx *c)
 }
 
 hipStream_t stream_of(const lfi_ctx *c);
+void note_kernel(const lfi_ctx *c, const char *name);
 uint32_t flags_of(const lfi_ctx *c);
 dim3 pixel_grid_of(const lfi_ctx *c);
 int cu_count_of(const lfi_ctx *c);
@@ -206,6 +231,7 @@ void launch_ten_direct(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     const int tiles_per_wg = 4 / vpw;
     const dim3 grid((n_tiles + tiles_per_wg - 1) / tiles_per_wg), block(256);
     hipStream_t st = stream_of(c);
+    note_kernel(c, "blend_ten_direct");
     if constexpr(PXL == 1 && MT == 2)
     {
         if(flags_of(c) & LFI_FLAG_TEN_ROUND_PER_BATCH)
@@ -231,6 +257,7 @@ void launch_ten_lds(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     const int n_tiles = tiles_x * a.height;
     const int passes = (a.v1 - a.v0 + VPP - 1) / VPP;
     const dim3 grid(n_tiles), block(WPX * WV * 64);
+    note_kernel(c, "blend_ten_lds");
     if(all_focus)
         hipLaunchKernelGGL((lfi::blend_ten_lds<NT, MT, WPX, WV, KC, WPE, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
     else
@@ -246,6 +273,7 @@ void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     const int passes = (a.v1 - a.v0 + VPP - 1) / VPP;
     // persistent: WGS workgroups per CU (2 x 80 KB of LDS at KC = 64), each walks tiles j, j+G, j+2G ...
     const dim3 grid(std::min(n_tiles, WGS * cu_count_of(c))), block(256);
+    note_kernel(c, STD ? (all_focus ? "blend_persist<STD,allfocus>" : "blend_persist<STD>") : (all_focus ? "blend_persist<TEN_WM,allfocus>" : "blend_persist<TEN_WM>"));
     if(all_focus)
         hipLaunchKernelGGL((lfi::blend_persist<STD, MT, true, NT_STORE, KC, WGS>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
     else
@@ -266,6 +294,7 @@ void launch_planar(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     const int n_tiles = tiles_x * a.out_rows;
     const int passes = (a.v1 - a.v0 + 63) / 64;
     const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    note_kernel(c, "blend_planar<TEN_WM>");
     hipLaunchKernelGGL((lfi::blend_planar<2, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, RING3);
 }
 
@@ -281,6 +310,7 @@ void launch_wave(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     const int tiles_x = (a.width + 127) / 128;
     const int n_tiles = tiles_x * a.out_rows;
     const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    note_kernel(c, STD ? "blend_wave<STD>" : "blend_wave<TEN_WM>");
     hipLaunchKernelGGL((lfi::blend_wave<STD, MT, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles);
 }
 
@@ -297,6 +327,7 @@ void launch_std_filtered(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     const int n_tiles = tiles_x * a.out_rows;
     const int passes = (a.v1 - a.v0 + 63) / 64;
     const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    note_kernel(c, "blend_planar<STDF>");
     hipLaunchKernelGGL((lfi::blend_planar<2, true, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, 0);
 }
 
@@ -309,6 +340,7 @@ void launch_std_mfma(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     const int vpw = passes >= 4 ? 4 : (passes >= 2 ? 2 : 1);
     const int tiles_per_wg = 4 / vpw;
     const dim3 grid((n_tiles + tiles_per_wg - 1) / tiles_per_wg), block(256);
+    note_kernel(c, "blend_std_mfma");
     if(all_focus)
         hipLaunchKernelGGL((lfi::blend_std_mfma<PXL, MT, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, vpw);
     else
@@ -317,6 +349,7 @@ void launch_std_mfma(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 
 void launch_std_valu(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
+    note_kernel(c, "blend_std_valu");
     if(all_focus)
         hipLaunchKernelGGL((lfi::blend_std_valu<true, 16>), pixel_grid_of(c), dim3(256), 0, stream_of(c), a);
     else
@@ -381,6 +414,7 @@ int check_render_args(lfi_ctx *c, int method, int v0, int v1)
 }
 
 hipStream_t stream_of(const lfi_ctx *c) { return c->stream; }
+void note_kernel(const lfi_ctx *c, const char *name) { c->last_kernel = name; }
 uint32_t flags_of(const lfi_ctx *c) { return c->flags; }
 dim3 pixel_grid_of(const lfi_ctx *c) { return pixel_grid(c); }
 int cu_count_of(const lfi_ctx *c) { return c->cu_count; }
@@ -440,7 +474,78 @@ bool wants_planar(const lfi_ctx *c, int method, int all_focus, const KernelArgs 
     return method == LFI_METHOD_STD && kStdVariants[c->std_variant].planar && c->weights_sum_ok && a.k_pad <= 64;
 }
 
+// planar view layout: does blend_p3 serve this launch?  (TEN_WM, fixed focus, weights in [0, 2) for the packed epilogue, no
+// debug modes; the planar input copy must be usable)
+bool wants_p3(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
+{
+    return c->out_layout == LFI_LAYOUT_PLANAR_RGB && method == LFI_METHOD_TEN_WM && !all_focus && !a.prequant && c->weights_scalable &&
+           !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) && kTenVariants[c->ten_variant].planar && a.k_pad <= 4 * lfi::P3_KC;
+}
+
+void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
+{
+    const int tiles_x = (a_in.width + lfi::P3_TPX - 1) / lfi::P3_TPX;
+    const int n_tiles = tiles_x * a_in.out_rows;
+    const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    const int nch = (a_in.k_pad + lfi::P3_KC - 1) / lfi::P3_KC;
+    note_kernel(c, "blend_p3<TEN_WM>");
+    // one launch per 64 views (a workgroup's four waves take 16 views each)
+    for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 64)
+    {
+        KernelArgs a = a_in;
+        a.v0 = v0;
+        a.v1 = std::min(v0 + 64, a_in.v1);
+        switch(nch)
+        {
+            case 1: hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
+            case 2: hipLaunchKernelGGL((lfi::blend_p3<true, 2>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
+            case 3: hipLaunchKernelGGL((lfi::blend_p3<true, 3>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
+            default: hipLaunchKernelGGL((lfi::blend_p3<true, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
+        }
+    }
+}
+
+int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in);
+
 int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
+{
+    if(c->out_layout != LFI_LAYOUT_PLANAR_RGB)
+        return launch_blend_rgba(c, method, all_focus, a_in);
+    if(wants_p3(c, method, all_focus, a_in) && ensure_planar(c))
+    {
+        KernelArgs a = a_in;
+        a.planar = c->planar;
+        a.planar_pitch = c->planar_pitch;
+        a.planar_padx = c->planar_padx;
+        launch_p3(c, a);
+        LFI_HIP(c, hipGetLastError());
+        return LFI_OK;
+    }
+    // every other render (STD, all-focus, debug modes, weights outside [0, 2)) goes through the RGBA kernels into a scratch copy of
+    // the views and is converted to byte planes afterwards
+    const size_t need = rgba_out_plane_bytes(c) * c->views_n;
+    if(c->rgba_scratch_bytes != need)
+    {
+        if(c->rgba_scratch)
+            (void)hipFree(c->rgba_scratch);
+        c->rgba_scratch = nullptr;
+        c->rgba_scratch_bytes = 0;
+        LFI_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->rgba_scratch), need));
+        c->rgba_scratch_bytes = need;
+    }
+    KernelArgs a = a_in;
+    a.views = c->rgba_scratch;
+    if(int rc = launch_blend_rgba(c, method, all_focus, a))
+        return rc;
+    const int pitch = view_pitch(c);
+    hipLaunchKernelGGL(lfi::views_rgba_to_planar, dim3((pitch / 4 + 255) / 256, c->out_rows, a.v1 - a.v0), dim3(256), 0, c->stream,
+                       reinterpret_cast<const uint32_t *>(c->rgba_scratch + rgba_out_plane_bytes(c) * a.v0), c->views + out_plane_bytes(c) * a.v0,
+                       c->width, c->out_rows, pitch);
+    LFI_HIP(c, hipGetLastError());
+    return LFI_OK;
+}
+
+int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
 {
     KernelArgs a = a_in;
     if(wants_planar(c, method, all_focus, a) && ensure_planar(c))
@@ -497,6 +602,40 @@ void free_views(lfi_ctx *c)
     c->views = nullptr;
     c->own_views = false;
     c->views_bytes = 0;
+    if(c->rgba_scratch)
+        (void)hipFree(c->rgba_scratch);
+    c->rgba_scratch = nullptr;
+    c->rgba_scratch_bytes = 0;
+    if(c->dl_plane)
+        (void)hipFree(c->dl_plane);
+    c->dl_plane = nullptr;
+    c->dl_plane_bytes = 0;
+}
+
+// device pointer and pitch of view v as an RGBA plane of out_rows rows: the view itself, or (planar layout) its expansion into the
+// context's one-plane staging buffer — valid until the next call, ordered on the context's stream
+int rgba_plane_of_view(lfi_ctx *c, int v, const uint8_t **out)
+{
+    if(c->out_layout != LFI_LAYOUT_PLANAR_RGB)
+    {
+        *out = c->views + out_plane_bytes(c) * v;
+        return LFI_OK;
+    }
+    const size_t need = rgba_out_plane_bytes(c);
+    if(c->dl_plane_bytes != need)
+    {
+        if(c->dl_plane)
+            (void)hipFree(c->dl_plane);
+        c->dl_plane = nullptr;
+        c->dl_plane_bytes = 0;
+        LFI_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->dl_plane), need));
+        c->dl_plane_bytes = need;
+    }
+    hipLaunchKernelGGL(lfi::view_planar_to_rgba, dim3(((c->width + 3) / 4 + 255) / 256, c->out_rows), dim3(256), 0, c->stream,
+                       c->views + out_plane_bytes(c) * v, reinterpret_cast<uint32_t *>(c->dl_plane), c->width, c->out_rows, view_pitch(c));
+    LFI_HIP(c, hipGetLastError());
+    *out = c->dl_plane;
+    return LFI_OK;
 }
 
 void free_grid(lfi_ctx *c)
@@ -739,7 +878,8 @@ int lfi_create(int device, lfi_ctx **out_ctx)
     c->device = device;
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if(hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+       hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming) != hipSuccess)
     {
         delete c;
         return fail(nullptr, LFI_EHIP, "could not create stream/events on the device");
@@ -762,6 +902,8 @@ int lfi_destroy(lfi_ctx *ctx)
         (void)hipEventDestroy(ctx->ev0);
     if(ctx->ev1)
         (void)hipEventDestroy(ctx->ev1);
+    if(ctx->ev_order)
+        (void)hipEventDestroy(ctx->ev_order);
     if(ctx->ev_fork)
         (void)hipEventDestroy(ctx->ev_fork);
     if(ctx->ev_pad)
@@ -780,7 +922,17 @@ int lfi_set_stream(lfi_ctx *ctx, void *hip_stream)
 {
     if(!ctx)
         return LFI_EINVAL;
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    if(next == ctx->stream)
+        return LFI_OK;
+    // The context keeps device state that launches on the new stream depend on and that may still be in flight on the old one: the
+    // input planes (lfi_fill_synthetic, uploads), the derived planar copy (planar_build), the focus maps and workspace, the views.
+    // Everything enqueued so far is ordered before everything enqueued from now on, without blocking the host.
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
+    LFI_HIP(ctx, hipStreamWaitEvent(next, ctx->ev_order, 0));
+    ctx->stream = next;
     return LFI_OK;
 }
 
@@ -916,10 +1068,16 @@ int lfi_broadcast_grid(lfi_ctx *const *ctxs, int n, int root)
     const Rccl &nc = rccl();
     if(!nc.ok)
         return fail(r0, LFI_EHIP, "librccl.so could not be loaded");
+    int caller_device = -1; // the loop below walks the contexts' devices; the caller's current device is restored afterwards
+    (void)hipGetDevice(&caller_device);
     std::vector<Rccl::comm_t> comms(n, nullptr);
     int rc = nc.CommInitAll(comms.data(), n, devs.data());
     if(rc != 0)
+    {
+        if(caller_device >= 0)
+            (void)hipSetDevice(caller_device);
         return fail(r0, LFI_EHIP, std::string("ncclCommInitAll: ") + nc.GetErrorString(rc));
+    }
     const size_t bytes = in_plane_bytes(r0) * r0->n;
     constexpr int NCCL_UINT8 = 1;
     int status = LFI_OK;
@@ -947,6 +1105,8 @@ int lfi_broadcast_grid(lfi_ctx *const *ctxs, int n, int root)
         (void)nc.CommDestroy(comms[i]);
         ctxs[i]->grid_version++;
     }
+    if(caller_device >= 0)
+        (void)hipSetDevice(caller_device);
     return status;
 }
 
@@ -973,19 +1133,28 @@ int lfi_grid_modified(lfi_ctx *ctx)
     return LFI_OK;
 }
 
-int lfi_fill_synthetic(lfi_ctx *ctx, uint32_t seed)
+int lfi_fill_synthetic_images(lfi_ctx *ctx, uint32_t seed, int g0, int g1)
 {
     if(!ctx)
         return LFI_EINVAL;
     if(!ctx->grid)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(g0 < 0 || g1 > ctx->n || g0 > g1)
+        return fail(ctx, LFI_EINVAL, "image range [g0, g1) outside the grid");
+    if(g0 == g1)
+        return LFI_OK;
     if(int rc = bind(ctx))
         return rc;
     ctx->grid_version++;
-    hipLaunchKernelGGL(lfi::fill_synthetic, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, ctx->n, ctx->width,
+    hipLaunchKernelGGL(lfi::fill_synthetic, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, g0, g1 - g0, ctx->width,
                        ctx->in_rows, ctx->in_y0, seed);
     LFI_HIP(ctx, hipGetLastError());
     return LFI_OK;
+}
+
+int lfi_fill_synthetic(lfi_ctx *ctx, uint32_t seed)
+{
+    return ctx ? lfi_fill_synthetic_images(ctx, seed, 0, ctx->n) : LFI_EINVAL;
 }
 
 int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
@@ -1124,7 +1293,7 @@ int lfi_attach_views(lfi_ctx *ctx, void *device_ptr, size_t bytes)
     if(!ctx->have_params)
         return fail(ctx, LFI_EINVAL, "lfi_set_params has not been called");
     if(!device_ptr || bytes < out_plane_bytes(ctx) * ctx->views_n)
-        return fail(ctx, LFI_EINVAL, "attached view buffer is NULL or smaller than V*rows*W*4 bytes");
+        return fail(ctx, LFI_EINVAL, "attached view buffer is NULL or smaller than the views in the current layout (lfi_view_layout)");
     if(reinterpret_cast<uintptr_t>(device_ptr) % 16)
         return fail(ctx, LFI_EINVAL, "attached view buffer must be 16-byte aligned");
     if(int rc = bind(ctx))
@@ -1133,6 +1302,52 @@ int lfi_attach_views(lfi_ctx *ctx, void *device_ptr, size_t bytes)
     free_views(ctx);
     ctx->views = static_cast<uint8_t *>(device_ptr);
     ctx->views_bytes = bytes;
+    return LFI_OK;
+}
+
+int lfi_set_output_layout(lfi_ctx *ctx, int layout)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(layout != LFI_LAYOUT_RGBA && layout != LFI_LAYOUT_PLANAR_RGB)
+        return fail(ctx, LFI_EINVAL, "unknown view layout");
+    if(!ctx->n)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(layout == ctx->out_layout)
+        return LFI_OK;
+    if(int rc = bind(ctx))
+        return rc;
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_views(ctx); // an attached buffer is dropped too: its size belongs to the old layout
+    ctx->out_layout = layout;
+    if(ctx->have_params)
+    {
+        ctx->views_bytes = out_plane_bytes(ctx) * ctx->views_n;
+        LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->views), ctx->views_bytes));
+        ctx->own_views = true;
+    }
+    return LFI_OK;
+}
+
+int lfi_view_layout(lfi_ctx *ctx, lfi_view_layout_info *out)
+{
+    if(!ctx || !out)
+        return LFI_EINVAL;
+    if(!ctx->n)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    out->layout = ctx->out_layout;
+    out->rows = ctx->out_rows;
+    if(ctx->out_layout == LFI_LAYOUT_PLANAR_RGB)
+    {
+        out->row_pitch_bytes = (size_t)view_pitch(ctx);
+        out->plane_stride_bytes = (size_t)ctx->out_rows * view_pitch(ctx);
+    }
+    else
+    {
+        out->row_pitch_bytes = (size_t)ctx->width * 4;
+        out->plane_stride_bytes = 0;
+    }
+    out->view_stride_bytes = out_plane_bytes(ctx);
     return LFI_OK;
 }
 
@@ -1192,6 +1407,45 @@ int lfi_render(lfi_ctx *ctx, int method, int all_focus, int v0, int v1)
         return rc;
     const KernelArgs a = make_args(ctx, v0, v1, method);
     return launch_blend(ctx, method, all_focus, a);
+}
+
+int lfi_prepare(lfi_ctx *ctx, int method, int all_focus, int v0, int v1)
+{
+    if(int rc = check_render_args(ctx, method, v0, v1))
+        return rc;
+    if(int rc = bind(ctx))
+        return rc;
+    const KernelArgs a = make_args(ctx, v0, v1, method);
+    ctx->derived_build_ms = 0.0f;
+    if(wants_planar(ctx, method, all_focus, a))
+    {
+        const uint64_t before = ctx->planar_version;
+        LFI_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        const bool ok = ensure_planar(ctx);
+        LFI_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        LFI_HIP(ctx, hipEventSynchronize(ctx->ev1));
+        if(ok && ctx->planar_version != before)
+            LFI_HIP(ctx, hipEventElapsedTime(&ctx->derived_build_ms, ctx->ev0, ctx->ev1));
+    }
+    return LFI_OK;
+}
+
+int lfi_memory_info(lfi_ctx *ctx, lfi_memory *out)
+{
+    if(!ctx || !out)
+        return LFI_EINVAL;
+    out->grid_bytes = ctx->grid ? in_plane_bytes(ctx) * ctx->n : 0;
+    out->derived_bytes = ctx->planar ? ctx->planar_bytes : 0;
+    out->views_bytes = ctx->views ? ctx->views_bytes : 0;
+    out->maps_bytes = ctx->maps ? plane_bytes(ctx) * 2 : 0;
+    out->workspace_bytes = ctx->focus_ws_bytes;
+    out->derived_build_ms = ctx->derived_build_ms;
+    return LFI_OK;
+}
+
+const char *lfi_last_kernel_name(const lfi_ctx *ctx)
+{
+    return ctx ? ctx->last_kernel : "";
 }
 
 int lfi_sync(lfi_ctx *ctx)
@@ -1285,7 +1539,10 @@ int lfi_download_view(lfi_ctx *ctx, int v, uint8_t *rgba, size_t pitch_bytes)
     if(int rc = bind(ctx))
         return rc;
     // rgba addresses row 0 of the whole view; the rows this context rendered are written at their place
-    LFI_HIP(ctx, hipMemcpy2DAsync(rgba + (size_t)ctx->out_y0 * pitch_bytes, pitch_bytes, ctx->views + out_plane_bytes(ctx) * v,
+    const uint8_t *src = nullptr;
+    if(int rc = rgba_plane_of_view(ctx, v, &src))
+        return rc;
+    LFI_HIP(ctx, hipMemcpy2DAsync(rgba + (size_t)ctx->out_y0 * pitch_bytes, pitch_bytes, src,
                                   (size_t)ctx->width * 4, (size_t)ctx->width * 4, ctx->out_rows, hipMemcpyDeviceToHost, ctx->stream));
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LFI_OK;
@@ -1325,7 +1582,10 @@ int lfi_download_quilt(lfi_ctx *ctx, int tiles_x, int tiles_y, int v0, uint8_t *
         {
             const int v = v0 + ty * tiles_x + tx;
             uint8_t *dst = rgba + ((size_t)ty * ctx->height + ctx->out_y0) * pitch_bytes + (size_t)tx * ctx->width * 4;
-            LFI_HIP(ctx, hipMemcpy2DAsync(dst, pitch_bytes, ctx->views + out_plane_bytes(ctx) * v, (size_t)ctx->width * 4,
+            const uint8_t *src = nullptr; // planar layout: expanded into the staging plane, which the copy below reads in stream order
+            if(int rc = rgba_plane_of_view(ctx, v, &src))
+                return rc;
+            LFI_HIP(ctx, hipMemcpy2DAsync(dst, pitch_bytes, src, (size_t)ctx->width * 4,
                                           (size_t)ctx->width * 4, ctx->out_rows, hipMemcpyDeviceToHost, ctx->stream));
         }
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1507,6 +1767,37 @@ int lfi_debug_mfma_f16(lfi_ctx *ctx, const uint16_t *a_32x16, const uint16_t *b_
     }
     if(e == hipSuccess)
         e = hipMemcpyAsync(c_32x32, d + 2048, 4096, hipMemcpyDeviceToHost, ctx->stream);
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    LFI_HIP(ctx, e);
+    return LFI_OK;
+}
+
+int lfi_debug_mfma_f16_chain(lfi_ctx *ctx, int shape, int k, const uint16_t *a_32xk, const uint16_t *b_kx32, float *c_32x32)
+{
+    if(!ctx || !a_32xk || !b_kx32 || !c_32x32 || (shape != 0 && shape != 1) || k < 32 || k > 256 || k % 32)
+        return LFI_EINVAL;
+    if(int rc = bind(ctx))
+        return rc;
+    const size_t ab = (size_t)32 * k * sizeof(uint16_t);
+    uint8_t *d = nullptr;
+    LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), 2 * ab + 4096));
+    hipError_t e = hipMemcpyAsync(d, a_32xk, ab, hipMemcpyHostToDevice, ctx->stream);
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(d + ab, b_kx32, ab, hipMemcpyHostToDevice, ctx->stream);
+    if(e == hipSuccess)
+    {
+        const uint16_t *da = reinterpret_cast<const uint16_t *>(d), *db = reinterpret_cast<const uint16_t *>(d + ab);
+        float *dc = reinterpret_cast<float *>(d + 2 * ab);
+        if(shape == 0)
+            hipLaunchKernelGGL(lfi::probe_mfma_f16_chain<0>, dim3(1), dim3(64), 0, ctx->stream, da, db, k, dc);
+        else
+            hipLaunchKernelGGL(lfi::probe_mfma_f16_chain<1>, dim3(1), dim3(64), 0, ctx->stream, da, db, k, dc);
+        e = hipGetLastError();
+    }
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(c_32x32, d + 2 * ab, 4096, hipMemcpyDeviceToHost, ctx->stream);
     if(e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);

@@ -125,8 +125,8 @@ void Interpolator::interpolate(std::string outputPath, std::string trajectory, f
 
     lfi::Parameterizer parameterizer(colsRows, resolution);
     lfi::HostParams params = parameterizer.build(trajectory, focus, range, effect, aspect, viewCount);
-    if(referenceMapQuirk)
-        params.flags |= LFI_FLAG_REFERENCE_MAP_QUIRK;
+    if(unifiedFocusMap)
+        params.flags |= LFI_FLAG_UNIFIED_FOCUS_MAP;
     if(gpuCount < 1 || gpuCount > viewCount)
         throw std::runtime_error("The number of GPUs has to be between 1 and the number of views!");
     shardOverGpus(params);

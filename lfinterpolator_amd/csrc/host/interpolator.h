@@ -22,7 +22,8 @@ class Interpolator
         void setViewCount(int count) { viewCount = count; }                // reference: always 64 (src/kernels.cu:11-13)
         void setBenchmarkRuns(size_t runs) { kernelBenchmarkRuns = runs; } // reference: 100 (src/interpolator.h:13)
         static void setDefaultDevice(int index) { defaultDevice = index; } // GPU used by Interpolator(path)
-        void setReferenceMapQuirk(bool on) { referenceMapQuirk = on; }
+        // all-focus TEN_WM reads the filtered map 1 like STD instead of the reference's map 0 (src/kernels.cu:430 vs :326)
+        void setUnifiedFocusMap(bool on) { unifiedFocusMap = on; }
         // also write quilt.png: the views as one image of cols × rows tiles (what scripts/viewsToQuilt.sh montages, 5×9 there)
         void setQuilt(lfi::IVec2 tiles) { quiltTiles = tiles; }
         float lastAverageTime() const { return averageTime; }
@@ -37,7 +38,7 @@ class Interpolator
         int viewCount{LFI_REFERENCE_VIEWS};
         static int defaultDevice;
         int device{defaultDevice};
-        bool referenceMapQuirk{false};
+        bool unifiedFocusMap{false};
         lfi::IVec2 quiltTiles{0, 0};
         lfi_ctx *context{nullptr};
         int gpuCount{1};

@@ -38,6 +38,7 @@ int main(int argc, char **argv)
                           "-g - number of GPUs: the views are split over GPUs d … d+g-1, the input grid is broadcast once (default=1)\n"
                           "-q - also store quilt.png: the first cols*rows views as cols,rows tiles (e.g. 5,9 for a Looking Glass quilt)\n"
                           "--synthetic cols,rows,width,height[,seed] - use a generated light field instead of -i\n"
+                          "--unified-map - all-focus TEN_WM reads the filtered focus map like STD (the reference reads the unfiltered one)\n"
                         };
     if(args.printHelpIfPresent(helpText))
         return 0;
@@ -84,6 +85,8 @@ int main(int argc, char **argv)
             interpolator->setGpuCount(static_cast<int>(args["-g"]));
         if(args["-b"])
             interpolator->setBenchmarkRuns(static_cast<size_t>(static_cast<int>(args["-b"])));
+        if(args["--unified-map"])
+            interpolator->setUnifiedFocusMap(true);
         if(args["-q"])
         {
             std::stringstream spec(static_cast<std::string>(args["-q"]));

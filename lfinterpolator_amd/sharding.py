@@ -35,6 +35,26 @@ def broadcast_grid(grid_tensor, src: int = 0):
     return grid_tensor
 
 
+def image_slice(n_images: int, world: int, rank: int) -> tuple[int, int]:
+    """Images [g0, g1) that rank `rank` produces (loads / generates) for the all-gather distribution: equal shares of
+    ceil(N / world) images, the last ranks' shares cut at N."""
+    per = -(-n_images // world)
+    return min(rank * per, n_images), min((rank + 1) * per, n_images)
+
+
+def allgather_grid(flat_tensor, rank: int, world: int):
+    """All-gather distribution of the light field: rank r has filled its slice of the input planes — bytes
+    [r·S, (r+1)·S) of `flat_tensor`, S = len / world (the tensor is padded to a multiple of world) — and ONE in-place all-gather
+    gives every rank everything.  Each rank sends 1/G of the bytes instead of rank 0 sending all of them: with xGMI's
+    point-to-point links every link carries 1/G of the grid, where a broadcast is bound by the root's links.  No-op for world 1."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        assert flat_tensor.numel() % world == 0
+        share = flat_tensor.numel() // world
+        dist.all_gather_into_tensor(flat_tensor, flat_tensor[rank * share:(rank + 1) * share].clone())
+    return flat_tensor
+
+
 # ---- row-band (spatial) sharding: each rank renders a band of rows of EVERY view and holds only the input rows the band's
 # warp reaches — per-GPU bytes shrink ≈1/G for inputs and outputs alike (view sharding re-reads the whole input on every rank)
 

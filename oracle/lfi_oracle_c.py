@@ -184,9 +184,13 @@ def _run_rows(fn, height, threads, rows=None):
     """ctypes drops the GIL during the call, so row bands run on `threads` host cores.
     rows=(y0, y1) restricts the computation to that band (the rest of the output stays zero)."""
     if rows is not None:
-        fn(int(rows[0]), int(rows[1]))
-        return
-    bands = _rows(height, threads)
+        y0, y1 = int(rows[0]), int(rows[1])
+        if threads <= 1 or y1 - y0 < 2:
+            fn(y0, y1)
+            return
+        bands = [(y0 + a, y0 + b) for a, b in _rows(y1 - y0, threads)]
+    else:
+        bands = _rows(height, threads)
     if len(bands) == 1:
         fn(*bands[0])
         return
@@ -248,7 +252,7 @@ def blend_f64(lf, focused, offs, weights_vn, v0=0, v1=None, all_focus=False, map
     return out
 
 
-def focus_estimate(lf, offs, ids, focus, rng, radius, threads=1):
+def focus_estimate(lf, offs, ids, focus, rng, radius, threads=1, rows=None):
     lf = np.ascontiguousarray(lf, dtype=np.uint8)
     n, h, w, _ = lf.shape
     off = np.ascontiguousarray(offs, dtype=np.float32)
@@ -256,15 +260,15 @@ def focus_estimate(lf, offs, ids, focus, rng, radius, threads=1):
     radius = np.ascontiguousarray(radius, dtype=np.int32)
     out = np.zeros((h, w, 4), dtype=np.uint8)
     _run_rows(lambda a, b: lib().lfo_focus_estimate(_p(lf), n, w, h, _p(off), _p(ids), len(ids), focus, rng,
-                                                     radius.ctypes.data_as(_i32p), a, b, _p(out)), h, threads)
+                                                     radius.ctypes.data_as(_i32p), a, b, _p(out)), h, threads, rows)
     return out
 
 
-def focus_filter(map0, radius, threads=1):
+def focus_filter(map0, radius, threads=1, rows=None):
     map0 = np.ascontiguousarray(map0, dtype=np.uint8)
     h, w = map0.shape[:2]
     radius = np.ascontiguousarray(radius, dtype=np.int32)
     out = np.zeros((h, w, 4), dtype=np.uint8)
     _run_rows(lambda a, b: lib().lfo_focus_filter(_p(map0), w, h, radius.ctypes.data_as(_i32p), a, b, _p(out)), h,
-              threads)
+              threads, rows)
     return out

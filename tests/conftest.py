@@ -38,10 +38,14 @@ def native():
 
 
 @pytest.fixture(scope="session")
-def gpu(native):
-    """A context factory on cuda:0.  No GPU → skip; a GPU without the built library → error (never a fallback)."""
+def gpu(native, request):
+    """A context factory on cuda:0.  A GPU without the built library is an error (never a fallback).  No GPU: an error too when
+    the GPU tests were asked for (`-m gpu`: a broken HIP environment must not read as "skipped"); a skip only when the GPU tests
+    were swept up by an unfiltered run on a machine without a device."""
     lib = native.load_hip_library()
     if lib.lfi_device_count() <= 0:
+        if "gpu" in (request.config.getoption("-m") or "") and "not gpu" not in request.config.getoption("-m"):
+            pytest.fail("-m gpu was requested but no HIP device is visible: " + lib.lfi_last_error(None).decode())
         pytest.skip("no HIP device on this machine")
     return native
 

@@ -54,10 +54,15 @@ def main():
         af_m16 = oc.blend_ten(lf, foc, off, w, model=oc.TEN_M16, all_focus=True, map_plane=map1, focus=focus, rng=rng)
         assert (af_m16 == on.blend_ten(lf, foc, off, w, model=on.TEN_M16, all_focus=True, map_plane=map1, focus=focus,
                                        rng=rng)).all()
+        # Tensors::process<true> reads the UNFILTERED map 0 (reference src/kernels.cu:430), Standard::process map 1 (:326): the
+        # library's default reproduces that; af_ten_m16 (map 1) is what LFI_FLAG_UNIFIED_FOCUS_MAP renders
+        af_m16_map0 = oc.blend_ten(lf, foc, off, w, model=oc.TEN_M16, all_focus=True, map_plane=map0, focus=focus, rng=rng)
+        assert (af_m16_map0 == on.blend_ten(lf, foc, off, w, model=on.TEN_M16, all_focus=True, map_plane=map0, focus=focus,
+                                            rng=rng)).all()
         path = os.path.join(GOLDEN_DIR, name + ".npz")
         np.savez_compressed(path, lf=lf, weights=w, offsets=off, focused=foc, ids=ids, radius=radius,
                             std=std, ten_m16=m16, ten_exact=exact, range=np.float32(rng), map0=map0, map1=map1,
-                            af_std=af_std, af_ten_m16=af_m16)
+                            af_std=af_std, af_ten_m16=af_m16, af_ten_m16_map0=af_m16_map0)
         print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 

@@ -118,11 +118,21 @@ def test_golden_fixtures(case, gpu, oracle_c):
         ctx.render("STD", all_focus=True)
         ctx.sync()
         assert (ctx.download_views() == g["af_std"]).all(), variant
+    # default: the reference's maps — Tensors::process<true> reads the unfiltered map 0 (src/kernels.cu:430)
     for variant in ctx.list_variants("TEN_WM"):
         ctx.set_variant("TEN_WM", variant)
         ctx.render("TEN_WM", all_focus=True)
         ctx.sync()
-        assert np.abs(ctx.download_views().astype(int) - g["af_ten_m16"].astype(int)).max() <= TEN_TOL_LSB, variant
+        assert np.abs(ctx.download_views().astype(int) - g["af_ten_m16_map0"].astype(int)).max() <= TEN_TOL_LSB, variant
+    # opt-in: both methods read the filtered map 1
+    ctx.set_params(hp, flags=gpu.LFI_FLAG_UNIFIED_FOCUS_MAP)
+    ctx.set_variant("TEN_WM", "auto")
+    ctx.render("TEN_WM", all_focus=True)
+    ctx.sync()
+    assert np.abs(ctx.download_views().astype(int) - g["af_ten_m16"].astype(int)).max() <= TEN_TOL_LSB
+    ctx.render("STD", all_focus=True)
+    ctx.sync()
+    assert (ctx.download_views() == g["af_std"]).all()
     ctx.close()
 
 
@@ -510,4 +520,116 @@ def test_std_rounding_band_adversarial(kind, gpu, oracle_c):
         ctx.sync()
         got = ctx.download_views()
         assert (got == want).all(), (kind, variant, int((got != want).sum()))
+    ctx.close()
+
+
+def _exact_products(a_bits, b_bits):
+    """Exact A·B of fp16 bit patterns as Python integers scaled by 2^48 (every fp16 is an integer multiple of 2^-24)."""
+    a = (a_bits.view(np.float16).astype(np.float64) * 2.0 ** 24).astype(object)
+    b = (b_bits.view(np.float16).astype(np.float64) * 2.0 ** 24).astype(object)
+    for m in (a, b):
+        for idx in np.ndindex(m.shape):
+            m[idx] = int(m[idx])
+    return a.dot(b)  # object matmul: exact integers, scale 2^-48
+
+
+@pytest.mark.parametrize("shape", [0, 1], ids=["32x32x16_chain", "16x16x32_chain"])
+def test_mfma_f16_accumulation_error_bound(shape, gpu):
+    """The default STD kernel (blend_planar<STDF>) rounds the fp16-MFMA sum wherever it is farther than
+    N·(2^-16 + 2^-15) + 2^-11 from a half-integer (csrc/hip/lfi_hip.hip make_args); the N·2^-15 part ASSUMES that the
+    matrix pipe's fp32 accumulation of the exactly representable products errs by at most one ulp of a value below 512 per
+    addend.  This measures it on operands built to expose alignment truncation, fed exactly as the kernel feeds them — weights
+    ×2^15 as the A operand, pixel bytes as fp16 subnormals (b·2^-24) as the B operand, acc = S·2^-9 — through 64-deep and 256-deep
+    chains of both MFMA shapes the kernels use: one product near the top of the range (255 · 0.99…) plus addends with all low
+    mantissa bits set 10–24 binades below it, plus sums that land just under the next binade."""
+    ctx = gpu.Context(0)
+    rng = np.random.default_rng(123)
+    worst = 0.0
+    for K in (64, 256):
+        a = np.zeros((32, K), np.float16)   # weights × 2^15 (exact in fp16 for weights in [0, 2))
+        b = np.zeros((K, 32), np.uint16)    # pixel bytes = mantissas of fp16 subnormals
+        for i in range(32):
+            kind = i % 4
+            w = np.zeros(K, np.float64)
+            if kind == 0:      # one dominant weight, the rest 2^-10 … 2^-24 with full 11-bit mantissas
+                w[0] = 2047.0 / 2048.0
+                e = rng.integers(10, 25, K - 1)
+                w[1:] = (2047.0 / 2048.0) * 2.0 ** (-e.astype(np.float64))
+            elif kind == 1:    # a convex combination with 11 significant bits each (what generateWeights produces, -s 7)
+                w = rng.random(K) ** 7
+                w /= w.sum()
+            elif kind == 2:    # equal weights 1/K (every addend the same binade: carries ripple through the whole sum)
+                w[:] = 1.0 / K
+            else:              # weights summing to just under 2 (sums up to 510: the top of the band's validity range)
+                w = rng.random(K)
+                w *= 1.999 / w.sum()
+            a[i] = (w.astype(np.float16).astype(np.float64) * 32768.0).astype(np.float16)
+        for j in range(32):
+            kind = j % 4
+            if kind == 0:
+                col = np.full(K, 255)
+            elif kind == 1:
+                col = rng.integers(0, 256, K)
+            elif kind == 2:
+                col = rng.integers(0, 256, K) | 1      # low bit always set
+                col[0] = 255
+            else:
+                col = np.where(np.arange(K) % 2 == 0, 255, 1)
+            b[:, j] = col
+        a_bits = a.view(np.uint16)
+        got = ctx.debug_mfma_f16_chain(a_bits, b, shape=shape).astype(np.float64)
+        exact = _exact_products(a_bits, b)
+        err = np.zeros((32, 32))
+        for idx in np.ndindex(32, 32):
+            err[idx] = abs(int(round(got[idx] * 2.0 ** 48)) - exact[idx]) / 2.0 ** 48   # fp32 values are multiples of 2^-48 here
+        # acc = S·2^-9: the kernel's assumption N·2^-15 on S is N·2^-24 on acc
+        bound = K * 2.0 ** -24
+        worst = max(worst, float(err.max() / bound))
+        assert err.max() <= bound, (K, float(err.max()), bound)
+        # and every sum is within half an ulp of SOME order of fp32 additions only if the pipe rounds once: report, do not require
+    print(f"MFMA f16 accumulation (shape {shape}): worst |error| = {worst:.4f} of the assumed bound K·2^-24")
+    ctx.close()
+
+
+def test_std_near_half_integer_sums_from_precise_weights(gpu, oracle_c):
+    """End-to-end companion of the accumulation-bound test: sums S that land within 2^-12 of x.5 (inside the rounding band, but
+    not exact ties) built from weights with ≥ 10 significant bits.  Zero offsets (focus 0), so output pixel x blends pixel x of
+    every image: for each pixel a vector of 64 bytes is searched whose exact blend with view 0's weights is that close to a
+    half-integer; the other views see the same pixels with other weights.  STD must stay bit-exact against the oracle."""
+    cols = rows = 8
+    n, W, H, V = 64, 256, 3, 64
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.0, 0.0, 7.0, 1.783, V)
+    assert (hp.focused_offsets == 0).all()
+    w0 = hp.weights[0].view(np.float16).astype(np.float64)
+    assert (np.frexp(w0[w0 > 0])[0] * 2048 % 2 == 1).mean() > 0.2   # plenty of weights use all 11 bits
+    rng = np.random.default_rng(77)
+    lf = np.zeros((n, H, W, 4), np.uint8)
+    lf[..., 3] = 255
+    found = 0
+    for y in range(H):
+        for c in range(3):
+            need = np.ones(W, bool)
+            while need.any():
+                cand = rng.integers(0, 256, (4096, n))
+                s = cand @ w0
+                close = np.abs(s - np.floor(s) - 0.5) < 2.0 ** -12
+                for row in cand[close]:
+                    idx = np.flatnonzero(need)
+                    if not len(idx):
+                        break
+                    lf[:, y, idx[0], c] = row
+                    need[idx[0]] = False
+                    found += 1
+    assert found == W * H * 3
+    ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    want = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)
+    for variant in ("auto", "wave_m2_nt"):
+        ctx.set_variant("STD", variant)
+        ctx.render("STD")
+        ctx.sync()
+        got = ctx.download_views()
+        assert (got == want).all(), (variant, int((got != want).sum()))
+    ctx.set_variant("STD", "auto")
+    ctx.render("STD")
+    assert ctx.last_kernel_name() == "blend_planar<STDF>"
     ctx.close()

@@ -101,7 +101,7 @@ def test_single_process_broadcast(gpu):
 
 def test_bench_json_contract(gpu):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                          "--prewarm-ms", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--prewarm-ms", "0", "--also-iters", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -118,6 +118,12 @@ def test_bench_json_contract(gpu):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "views/s" and "sample" in c
     assert d["value"] > 100 * c["value"]
+    assert r["frac_moved"] <= r["frac"] + 1e-9 and d["config"]["derived_copy_bytes"] > 0 and d["config"]["kernel"]
+    # the other BASELINE configurations, timed in the same run
+    also = d["also"]
+    for key in ("config2_std", "config2_std_valu", "config3", "config4_rank", "config4_whole_1gpu", "config5_fixed_focus",
+                "config5_focus_map", "config5_allfocus_ten_wm_end_to_end", "config5_allfocus_std_end_to_end"):
+        assert key in also and also[key]["ms"] > 0 and 0 < also[key]["frac"] < 1.2 and also[key]["kernel"], key
 
 
 def test_pinned_host_buffers(gpu, oracle_c):
@@ -193,4 +199,38 @@ def test_input_changes_reach_the_renders(gpu, oracle_c):
     ctx.render("TEN_WM"); ctx.sync()
     w2 = oracle_c.blend_ten(lf_a, hp2.focused_offsets, hp2.offsets, hp2.weights, model=oracle_c.TEN_M16)
     assert np.abs(ctx.download_views().astype(int) - w2.astype(int)).max() <= 1
+    ctx.close()
+
+
+def test_stream_switch_orders_derived_state(gpu):
+    """The context keeps derived device state (the planar copy of the inputs, built asynchronously on whatever stream is
+    current; the synthetic fill itself) that launches on ANOTHER stream depend on.  lfi_set_stream orders the old stream's work
+    before the new stream's (an event, no host sync): a render that switches streams right after a large fill + planar build
+    must produce the bytes of a fully synchronised render."""
+    import torch
+    cols = rows = 8
+    W, H, V = 1920, 540, 8          # large enough that fill (265 MB) + planar_build are still running when the next launch is enqueued
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.23, 0.0, 3.0, 1.783, V)
+    ref = gpu.Context(0)
+    ref.set_grid(cols, rows, W, H)
+    ref.fill_synthetic(31)
+    ref.set_params(hp)
+    ref.render("TEN_WM")
+    ref.sync()
+    want = ref.download_views()
+    ref.close()
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.set_params(hp)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for seed in (7, 31):            # the second round also exercises the rebuild of the planar copy after a change of the inputs
+        ctx.set_stream(s1.cuda_stream)
+        ctx.fill_synthetic(seed)    # asynchronous on s1
+        ctx.render("TEN_WM")        # builds the planar copy on s1, renders on s1
+        ctx.fill_synthetic(seed)    # inputs "change" again: the copy is stale, the next render rebuilds it …
+        ctx.set_stream(s2.cuda_stream)
+        ctx.render("TEN_WM")        # … on s2, which must wait for the fill still running on s1
+        s2.synchronize()
+    ctx.set_stream(None)
+    assert (ctx.download_views() == want).all()
     ctx.close()

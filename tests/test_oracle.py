@@ -90,6 +90,8 @@ def test_oracles_reproduce_golden(case, oracle_c, oracle_np):
     assert (oracle_c.focus_filter(map0, g["radius"]) == g["map1"]).all()
     assert (oracle_c.blend_std(lf, foc, off, w, all_focus=True, map_plane=g["map1"], focus=focus, rng=rng) == g["af_std"]).all()
     assert (oracle_c.blend_ten(lf, foc, off, w, all_focus=True, map_plane=g["map1"], focus=focus, rng=rng) == g["af_ten_m16"]).all()
+    # the reference's tensor kernel reads the unfiltered map (src/kernels.cu:430)
+    assert (oracle_c.blend_ten(lf, foc, off, w, all_focus=True, map_plane=g["map0"], focus=focus, rng=rng) == g["af_ten_m16_map0"]).all()
 
 
 def test_oracle_properties(oracle_c):

@@ -17,7 +17,7 @@ variants = dict(v.split("=") for v in sys.argv[1:])   # e.g. TEN_WM=wave_m2_nt S
 for meth, var in variants.items():
     ctx.set_variant(meth, var)
 for name, mv in maps.items():
-    ctx.upload_map(1, map_of(mv))
+    ctx.upload_map(0, map_of(mv)); ctx.upload_map(1, map_of(mv))  # TEN_WM reads map 0, STD map 1 (reference defaults)
     out = []
     for method in ("TEN_WM", "STD"):
         st = ctx.benchmark(method, all_focus=True, warmup=2, runs=5)

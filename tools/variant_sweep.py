@@ -26,7 +26,7 @@ def parity(cols, rows, W, H, V, traj="0,0,1,1", focus=0.23, aspect=1.783, effect
     m = None
     if af:
         m = oc.synthetic_lf(1, W, H, 77)[0]
-        ctx.upload_map(1, m)
+        ctx.upload_map(0, m); ctx.upload_map(1, m)  # TEN_WM reads map 0, STD map 1 (reference defaults)
     ref_std = oc.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, threads=8, all_focus=af, map_plane=m, focus=focus, rng=rng)
     ref_ex = oc.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, model=oc.TEN_EXACT, threads=8, all_focus=af, map_plane=m, focus=focus, rng=rng)
     ref_m16 = oc.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, model=oc.TEN_M16, threads=8, all_focus=af, map_plane=m, focus=focus, rng=rng)
