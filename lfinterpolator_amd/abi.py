@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
     "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
-    "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_debug_mfma_f16_chain",
+    "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_fill_synthetic_scene", "lfi_debug_mfma_f16_chain",
 ]
 
 
@@ -114,6 +114,7 @@ def load_hip_library() -> C.CDLL:
         "lfi_download_prequant": (i, [vp, i, i, i, vp]),
         "lfi_debug_mfma_f16": (i, [vp, vp, vp, vp]),
         "lfi_prepare": (i, [vp, i, i, i, i]),
+        "lfi_fill_synthetic_scene": (i, [vp, C.c_uint32, C.c_float, C.c_float]),
         "lfi_debug_mfma_f16_chain": (i, [vp, i, i, vp, vp, vp]),
         "lfi_set_output_layout": (i, [vp, i]),
         "lfi_view_layout": (i, [vp, C.POINTER(ViewLayout)]),
@@ -225,6 +226,10 @@ class Context:
             self._check(self._lib.lfi_fill_synthetic(self._h, seed))
         else:
             self._check(self._lib.lfi_fill_synthetic_images(self._h, seed, g0 or 0, self.n_images if g1 is None else g1))
+
+    def fill_synthetic_scene(self, seed: int, focus_lo: float, focus_hi: float) -> None:
+        """Structured light field (texture at a piecewise-constant focus) for focus-map timing; call after set_params."""
+        self._check(self._lib.lfi_fill_synthetic_scene(self._h, seed, focus_lo, focus_hi))
 
     # -- parameters --------------------------------------------------------------------------------------------
     def set_params(self, hp, flags: int = 0) -> None:

@@ -51,8 +51,12 @@ __host__ __device__ constexpr int p3_octet_off(int o)
 #define LFI_P3_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // planar views: plane (view, channel) at ((view·3 + channel)·rows)·pitch, pixel x of row y at y·pitch + x
-template <bool NT_STORE, int NCH>
-__global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int tiles_x, const int n_tiles)
+// view_passes > 1 (more than 64 views; NCH == 1 only — the host splits other launches): the tile stays in LDS for every pass, the
+// weight fragments of the next pass are fetched while the current one computes.
+// ABL (measurement builds only, LFI_P3_ABLATE): 0 = the kernel; 1 = no k-loop (DMA + barriers + stores of zeros); 2 = no DMA (the
+// k-loop runs on whatever LDS holds); 3 = no stores.  Outputs of ABL != 0 are garbage by construction.
+template <bool NT_STORE, int NCH, int ABL = 0>
+__global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[3 * P3_BUF_B + LFI_MAX_IMAGES * 8];
 
@@ -69,19 +73,22 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
         off_table[g] = make_int2(o.x, o.y);
     }
 
-    // this wave's 16 views: all their weights, as MFMA A fragments (k-step s = images 32s … 32s+31)
-    const int vw = a.v0 + 16 * wave;
-    const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw, 16)); // ≤ 0: this wave only helps with the DMA
-    half8 wreg[2 * NCH];
+    // this wave's 16 views of a pass (views v0 + 64·pass + 16·wave …): all their weights, as MFMA A fragments (k-step s = images
+    // 32s … 32s+31)
+    const int vw0 = a.v0 + 16 * wave;
+    auto load_weights = [&](const int pass, half8 (&w_out)[2 * NCH]) {
 #pragma unroll
-    for(int s = 0; s < 2 * NCH; s++)
-    {
-        const int k = 32 * s + 8 * kg;
-        u32x4 w = {0u, 0u, 0u, 0u};
-        if(k < a.k_pad) // rows are k_pad halves long (a multiple of 16): nothing is read across a row's end
-            w = *reinterpret_cast<const u32x4 *>(a.w16s + (size_t)(vw + n) * a.k_pad + k);
-        wreg[s] = __builtin_bit_cast(half8, w);
-    }
+        for(int s = 0; s < 2 * NCH; s++)
+        {
+            const int k = 32 * s + 8 * kg;
+            u32x4 w = {0u, 0u, 0u, 0u};
+            if(k < a.k_pad) // rows are k_pad halves long (a multiple of 16): nothing is read across a row's end
+                w = *reinterpret_cast<const u32x4 *>(a.w16s + (size_t)(vw0 + 64 * pass + n) * a.k_pad + k);
+            w_out[s] = __builtin_bit_cast(half8, w);
+        }
+    };
+    half8 wreg[2 * NCH];
+    load_weights(0, wreg);
     // the loads above are the only vector loads the compiler knows about: make it wait for them HERE, before any LDS-DMA is in
     // flight, instead of with a vmcnt(0) in front of the first MFMA (which would also drain the pipeline's first three tiles)
 #pragma unroll
@@ -134,10 +141,15 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
             const int start = x0 + pc.ox[o2] + a.planar_padx;
             const int k = start & 3;
             const uint8_t *src = a.planar + pc.plane0[o2] + ((size_t)k * a.in_rows + sy) * a.planar_pitch + (start - k) + 16 * (lane & 7);
+            if constexpr(ABL != 2)
+            {
 #pragma unroll
-            for(int ch = 0; ch < 3; ch++)
-                dma16(src + (size_t)ch * 4 * shift_stride, dst + uint32_t(ch * P3_CH_B + p3_octet_off(octet)));
-            count += 3;
+                for(int ch = 0; ch < 3; ch++)
+                    dma16(src + (size_t)ch * 4 * shift_stride, dst + uint32_t(ch * P3_CH_B + p3_octet_off(octet)));
+                count += 3;
+            }
+            else
+                asm volatile("" ::"v"(src), "s"(dst));
         }
         return count;
     };
@@ -152,6 +164,8 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
     // k-loop of one unit from buffer `buf`: wk = the chunk's two weight fragments
     const uint32_t lane_px = uint32_t(1024 * kg + 128 * ((kg + 1) >> 1) + 8 * n); // p3_octet_off(kg) + this lane's 8 pixels
     auto compute = [&](const half8 (&wk)[2], const int buf, const int kc) {
+        if constexpr(ABL == 1)
+            return;
         const uint8_t *pb = lds + buf * P3_BUF_B + lane_px;
 #pragma unroll
         for(int ks = 0; ks < 2; ks++)
@@ -185,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
     // epilogue of tile t: quantise (acc = S·2^-9), pack eight pixels per (view, channel), store; returns the number of store
     // instructions issued (wave-uniform); clears acc
     const uint32_t plane_b = uint32_t(a.out_rows) * uint32_t(a.views_pitch); // bytes of one byte plane (< 2^26·… checked on the host)
-    auto epilogue = [&](const int t) {
+    auto epilogue = [&](const int t, const int vw, const int nvalid) {
         const int ty = t / tiles_x; // row inside the output window
         const int x0 = (t - ty * tiles_x) * P3_TPX;
         uint32_t hq[48]; // [(i·3 + channel)·4 + block pair]: two halves, 0x4000 | byte after the rounding-mode window
@@ -234,6 +248,11 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
                 const u32x2 px8 = {__builtin_amdgcn_perm(q[1], q[0], 0x06040200u),  // pixels 8n … 8n+3
                                    __builtin_amdgcn_perm(q[3], q[2], 0x06040200u)}; // pixels 8n+4 … 8n+7
                 u32x2 *out = reinterpret_cast<u32x2 *>(ubase + (size_t)(3 * i + ch) * plane_b + lane_off);
+                if constexpr(ABL == 3)
+                {
+                    asm volatile("" ::"v"(px8), "v"(out));
+                    continue;
+                }
                 n_st++;
                 if(x_ok && 4 * kg + i < nvalid)
                 {
@@ -305,24 +324,54 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
                 pc = lookup(ic); // for the unit after that: off the critical path of the next barrier
         }
         const int kc = min(P3_KC, a.k_pad - P3_KC * cc);
-        if(nvalid > 0)
-        {
-            // the chunk's fragments by wave-uniform selects over compile-time register indices (a runtime index would put wreg
-            // into scratch, and scratch accesses would enter the vmcnt queue the waits above count)
-            half8 wk[2] = {wreg[0], wreg[1]};
-#pragma unroll
-            for(int c = 1; c < NCH; c++)
-                if(cc == c)
-                {
-                    wk[0] = wreg[2 * c];
-                    wk[1] = wreg[2 * c + 1];
-                }
-            compute(wk, buf, kc);
-        }
         st2 = st1;
         st1 = 0;
-        if(cc == NCH - 1 && nvalid > 0)
-            st1 = epilogue(ct);
+        if constexpr(NCH == 1)
+        {
+            // every view pass of the tile from the same LDS buffer.  The next pass's weight fragments (pass 0's for the next tile
+            // after the last pass) are loaded ahead with ordinary loads: the compiler waits for them where wreg is overwritten, by
+            // which time they have long arrived; they are OLDER than that wait's stores, so the hand-counted waits above stay
+            // valid as long as they count only operations that were certainly issued (the stores and the DMA, not these loads).
+            for(int pass = 0; pass < view_passes; pass++)
+            {
+                half8 wnext[2];
+                if(view_passes > 1)
+                    load_weights(pass + 1 == view_passes ? 0 : pass + 1, wnext);
+                const int vw = vw0 + 64 * pass;
+                const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw, 16)); // ≤ 0: nothing to do for this wave
+                if(nvalid > 0)
+                {
+                    const half8 wk[2] = {wreg[0], wreg[1]};
+                    compute(wk, buf, kc);
+                    st1 += epilogue(ct, vw, nvalid);
+                }
+                if(view_passes > 1)
+                {
+                    wreg[0] = wnext[0];
+                    wreg[1] = wnext[1];
+                }
+            }
+        }
+        else
+        {
+            const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw0, 16)); // ≤ 0: this wave only helps with the DMA
+            if(nvalid > 0)
+            {
+                // the chunk's fragments by wave-uniform selects over compile-time register indices (a runtime index would put
+                // wreg into scratch, and scratch accesses would enter the vmcnt queue the waits above count)
+                half8 wk[2] = {wreg[0], wreg[1]};
+#pragma unroll
+                for(int c = 1; c < NCH; c++)
+                    if(cc == c)
+                    {
+                        wk[0] = wreg[2 * c];
+                        wk[1] = wreg[2 * c + 1];
+                    }
+                compute(wk, buf, kc);
+                if(cc == NCH - 1)
+                    st1 = epilogue(ct, vw0, nvalid);
+            }
+        }
         if(!have1)
             break;
         if(++cc == NCH)

@@ -91,6 +91,105 @@ __global__ void __launch_bounds__(256) blend_std_valu(const KernelArgs a)
     }
 }
 
+// The non-tensor wavefront kernel (north_star: "the non-tensor path kept as a coalesced-HBM wavefront kernel"): one pixel per lane,
+// ONE pass over the inputs for 64 views — 192 fp32 accumulators per lane as 96 register pairs, v_pk_fma_f32 on (view 2j, view 2j+1)
+// pairs with the pair's weights in an SGPR pair (scalar loads of w32t rows: wave-uniform) and the pixel value broadcast to both
+// halves; each accumulator still sees its images in ascending order, one IEEE fma per image: the reference's chain, bit for bit
+// (src/kernels.cu:292-299, 328-338).  The pixel of image g + 2 is fetched while image g is accumulated (two waves per SIMD cover
+// the rest of the latency); a half-wave reads 128 contiguous bytes per image row, stores are 256 contiguous bytes per view.
+// Bound: the fp32 vector pipe — 6·N·V flops per pixel at 157.3 TFLOP/s.
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+template <bool ALLFOCUS>
+__global__ void __launch_bounds__(256, 2) blend_std_vfma(const KernelArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = a.width, H = a.height;
+    if(y >= H)
+        return;
+    const bool x_ok = x < W;
+    const int xc = min(x, W - 1);
+    const size_t plane_px = (size_t)W * (size_t)H;
+    const uint32_t *grid32 = reinterpret_cast<const uint32_t *>(a.grid);
+    // offsets and weights are read through the constant address space: wave-uniform scalar loads (lgkmcnt), which also keeps the
+    // vector-memory queue to the pixel fetches (the compiler cannot prove by itself that the views do not alias them)
+    typedef const __attribute__((address_space(4))) int32_t *const_int_ptr;
+    typedef const __attribute__((address_space(4))) float *const_float_ptr;
+    const const_int_ptr c_focused = (const_int_ptr)(uintptr_t)a.focused;
+    const const_float_ptr c_offsets = (const_float_ptr)(uintptr_t)a.offsets;
+    const const_float_ptr c_w32t = (const_float_ptr)(uintptr_t)a.w32t;
+    float focus_px = 0.0f;
+    if constexpr(ALLFOCUS)
+        focus_px = decode_focus(a.maps + (size_t)a.map_index * plane_px * 4, W, H, xc, y, a.focus, a.range);
+    auto fetch = [&](const int g) {
+        int sx, sy;
+        if constexpr(ALLFOCUS)
+        {
+            sx = warp_float(xc, focus_px, c_offsets[2 * g]);
+            sy = warp_float(y, focus_px, c_offsets[2 * g + 1]);
+        }
+        else
+        {
+            sx = xc + c_focused[2 * g];
+            sy = y + c_focused[2 * g + 1];
+        }
+        return grid32[(size_t)g * plane_px + (size_t)clampi(sy, 0, H - 1) * W + clampi(sx, 0, W - 1)];
+    };
+    const int n = a.n_images;
+    for(int vb = a.v0; vb < a.v1; vb += 64)
+    {
+        float2v acc[32][3];
+#pragma unroll
+        for(int j = 0; j < 32; j++)
+#pragma unroll
+            for(int c = 0; c < 3; c++)
+                acc[j][c] = float2v{0.0f, 0.0f};
+        uint32_t p0 = fetch(0), p1 = fetch(min(1, n - 1));
+        for(int g = 0; g < n; g++) // ascending g: src/kernels.cu:328
+        {
+            const uint32_t p2 = fetch(min(g + 2, n - 1));
+            const float pr = static_cast<float>(p0 & 0xffu), pg = static_cast<float>((p0 >> 8) & 0xffu), pb = static_cast<float>((p0 >> 16) & 0xffu);
+            const float2v r2 = {pr, pr}, g2 = {pg, pg}, b2 = {pb, pb};
+            const const_float_ptr wrow = c_w32t + (size_t)g * a.v_pad + vb; // rows are padded to 64 + 64 views
+#pragma unroll
+            for(int j = 0; j < 32; j++)
+            {
+                const float2v w2 = {wrow[2 * j], wrow[2 * j + 1]};
+                acc[j][0] = __builtin_elementwise_fma(r2, w2, acc[j][0]);
+                acc[j][1] = __builtin_elementwise_fma(g2, w2, acc[j][1]);
+                acc[j][2] = __builtin_elementwise_fma(b2, w2, acc[j][2]);
+            }
+            p0 = p1;
+            p1 = p2;
+        }
+        uint32_t *out = reinterpret_cast<uint32_t *>(a.views) + (size_t)vb * plane_px + (size_t)y * W + x;
+#pragma unroll
+        for(int j = 0; j < 32; j++)
+#pragma unroll
+            for(int e = 0; e < 2; e++)
+            {
+                const int view = vb + 2 * j + e;
+                if(view < a.v1 && x_ok)
+                {
+                    // uch4 (src/kernels.cu:301-310): sum + 2^23 leaves (unsigned char)__float2int_rn(sum) in the low mantissa byte
+                    const uint32_t tr = __builtin_bit_cast(uint32_t, acc[j][0][e] + 8388608.0f), tg = __builtin_bit_cast(uint32_t, acc[j][1][e] + 8388608.0f),
+                                   tb = __builtin_bit_cast(uint32_t, acc[j][2][e] + 8388608.0f);
+                    const uint32_t rg = __builtin_amdgcn_perm(tg, tr, 0x0c0c0400u);
+                    __builtin_nontemporal_store(__builtin_amdgcn_perm(tb, rg, 0x0d040100u), out + (size_t)(2 * j + e) * plane_px);
+                    if(a.prequant != nullptr && view == a.prequant_view)
+                    {
+                        float *pq = a.prequant + ((size_t)y * W + x) * 3;
+                        pq[0] = acc[j][0][e];
+                        pq[1] = acc[j][1][e];
+                        pq[2] = acc[j][2][e];
+                    }
+                }
+            }
+    }
+}
+
 // Same tiling as blend_ten_direct (one wave = 32*PXL pixels of a row × 32*MT views per pass) on the exact-f32 MFMA.
 template <int PXL, int MT, bool ALLFOCUS>
 __global__ void __launch_bounds__(256) blend_std_mfma(const KernelArgs a, const int tiles_x, const int n_tiles,

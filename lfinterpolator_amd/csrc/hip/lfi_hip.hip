@@ -187,9 +187,11 @@ KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
     a.v1 = v1;
     a.n_focus_ids = c->n_focus_ids;
     a.planar = nullptr; // set by launch_blend when the copy is valid for this launch
-    // blend_planar<STDF>: chain bound N·2^-16 (half an ulp below 512 per fmaf) + MFMA accumulation bound N·2^-15 (a whole ulp per
-    // addition, as if each truncated) + 2^-11 of margin
-    a.std_band = float(c->n) * (0x1p-16f + 0x1p-15f) + 0x1p-11f;
+    // blend_planar<STDF>: chain bound N·2^-16 (half an ulp below 512 per fmaf: arithmetic) + MFMA accumulation bound N·2^-17 (a
+    // quarter ulp per addend: MEASURED on gfx950 — chains of v_mfma_f32_32x32x16_f16 on operands built to expose alignment
+    // truncation stay within 0.086 ulp per addend, tests/test_gpu_parity.py::test_mfma_f16_accumulation_error_bound asserts the
+    // quarter ulp used here) + 2^-11 of margin
+    a.std_band = float(c->n) * (0x1p-16f + 0x1p-17f) + 0x1p-11f;
     a.planar_pitch = c->planar_pitch;
     a.planar_padx = c->planar_padx;
     a.views_pitch = view_pitch(c);
@@ -356,6 +358,15 @@ void launch_std_valu(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
         hipLaunchKernelGGL((lfi::blend_std_valu<false, 16>), pixel_grid_of(c), dim3(256), 0, stream_of(c), a);
 }
 
+void launch_std_vfma(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    note_kernel(c, "blend_std_vfma");
+    if(all_focus)
+        hipLaunchKernelGGL((lfi::blend_std_vfma<true>), pixel_grid_of(c), dim3(256), 0, stream_of(c), a);
+    else
+        hipLaunchKernelGGL((lfi::blend_std_vfma<false>), pixel_grid_of(c), dim3(256), 0, stream_of(c), a);
+}
+
 // first entry = default ("auto")
 const Variant kTenVariants[] = {
     {"planar_m2_nt", launch_planar<true>, true, false, true, true}, // blend_persist where blend_planar does not apply
@@ -381,7 +392,7 @@ const Variant kStdVariants[] = {
     {"persist_m2_nt", launch_persist<true, 2, true>, false, false, true},
     {"persist_m1_nt", launch_persist<true, 1, true>, false, false, true},
     {"mfma_p1m2", launch_std_mfma<1, 2>, false, true}, {"mfma_p2m2", launch_std_mfma<2, 2>, false, true}, {"mfma_p2m1", launch_std_mfma<2, 1>, false, true},
-    {"mfma_p4m1", launch_std_mfma<4, 1>, false, true}, {"valu", launch_std_valu, false, true},
+    {"mfma_p4m1", launch_std_mfma<4, 1>, false, true}, {"valu", launch_std_valu, false, true}, {"vfma", launch_std_vfma, false, true},
 };
 const int kNumTenVariants = sizeof(kTenVariants) / sizeof(kTenVariants[0]);
 const int kNumStdVariants = sizeof(kStdVariants) / sizeof(kStdVariants[0]);
@@ -489,7 +500,34 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
     const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
     const int nch = (a_in.k_pad + lfi::P3_KC - 1) / lfi::P3_KC;
     note_kernel(c, "blend_p3<TEN_WM>");
-    // one launch per 64 views (a workgroup's four waves take 16 views each)
+    // measurement builds (tools/p3_ablate.py): where does a unit's time go?  Never set in production; outputs are garbage.
+    static const int ablate = [] {
+        const char *e = std::getenv("LFI_P3_ABLATE");
+        return e ? std::atoi(e) : 0;
+    }();
+    if(ablate >= 1 && ablate <= 3 && (nch == 1 || nch == 4) && a_in.v1 - a_in.v0 <= 64)
+    {
+        note_kernel(c, "blend_p3<ABLATION>");
+#define LFI_P3_ABL(N, A) hipLaunchKernelGGL((lfi::blend_p3<true, N, A>), grid, block, 0, stream_of(c), a_in, tiles_x, n_tiles, 1)
+        if(nch == 1)
+        {
+            if(ablate == 1) LFI_P3_ABL(1, 1); else if(ablate == 2) LFI_P3_ABL(1, 2); else LFI_P3_ABL(1, 3);
+        }
+        else
+        {
+            if(ablate == 1) LFI_P3_ABL(4, 1); else if(ablate == 2) LFI_P3_ABL(4, 2); else LFI_P3_ABL(4, 3);
+        }
+#undef LFI_P3_ABL
+        return;
+    }
+    if(nch == 1)
+    {
+        // one chunk of images: every 64-view pass of a tile reads the same LDS-resident pixels (inputs fetched once per launch)
+        const int passes = (a_in.v1 - a_in.v0 + 63) / 64;
+        hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a_in, tiles_x, n_tiles, passes);
+        return;
+    }
+    // several chunks: one launch per 64 views (a workgroup's four waves take 16 views each)
     for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 64)
     {
         KernelArgs a = a_in;
@@ -497,10 +535,9 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
         a.v1 = std::min(v0 + 64, a_in.v1);
         switch(nch)
         {
-            case 1: hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
-            case 2: hipLaunchKernelGGL((lfi::blend_p3<true, 2>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
-            case 3: hipLaunchKernelGGL((lfi::blend_p3<true, 3>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
-            default: hipLaunchKernelGGL((lfi::blend_p3<true, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
+            case 2: hipLaunchKernelGGL((lfi::blend_p3<true, 2>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1); break;
+            case 3: hipLaunchKernelGGL((lfi::blend_p3<true, 3>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1); break;
+            default: hipLaunchKernelGGL((lfi::blend_p3<true, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1); break;
         }
     }
 }
@@ -1148,6 +1185,21 @@ int lfi_fill_synthetic_images(lfi_ctx *ctx, uint32_t seed, int g0, int g1)
     ctx->grid_version++;
     hipLaunchKernelGGL(lfi::fill_synthetic, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, g0, g1 - g0, ctx->width,
                        ctx->in_rows, ctx->in_y0, seed);
+    LFI_HIP(ctx, hipGetLastError());
+    return LFI_OK;
+}
+
+int lfi_fill_synthetic_scene(lfi_ctx *ctx, uint32_t seed, float focus_lo, float focus_hi)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->grid || !ctx->have_params)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid / lfi_set_params have not been called (the scene is built from the images' offsets)");
+    if(int rc = bind(ctx))
+        return rc;
+    ctx->grid_version++;
+    hipLaunchKernelGGL(lfi::fill_scene, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, ctx->d_offsets, ctx->n, ctx->width, ctx->in_rows,
+                       ctx->in_y0, seed, focus_lo, focus_hi);
     LFI_HIP(ctx, hipGetLastError());
     return LFI_OK;
 }

@@ -42,6 +42,51 @@ __device__ __forceinline__ void xcd_range(uint32_t b, uint32_t nb, uint32_t n_ti
 enum { OUT_RGBA = 0, OUT_PLANAR = 1, OUT_RGB24 = 2, OUT_RGB24_X3 = 3, OUT_NONE = 4 };
 
 // persistent: grid = 2 x CUs x ..., tiles t, t+G, ...   MAP: 0 = batches of G tiles split over the XCDs (blend_planar today), 1 = xcd_range
+// wider tiles: runs of TW bytes per (image, channel) and per (view, channel) plane row — does the memory system prefer longer runs?
+template <int TW, bool WRITE>
+__global__ void __launch_bounds__(256) k_wide(const uint8_t *__restrict__ planar, uint8_t *__restrict__ views, const Offs offs, const int pitch, const int padx,
+                                              const int tiles_x, const int n_tiles)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t shift_stride = (size_t)H * pitch;
+    constexpr int LPR = TW / 16;       // lanes per run
+    constexpr int RPI = 64 / LPR;      // runs per load instruction
+    constexpr int NLOAD = 192 / RPI / 4; // load instructions per wave and tile
+    for(uint32_t t = xcd_contig(blockIdx.x, gridDim.x); t < (uint32_t)n_tiles; t += gridDim.x)
+    {
+        const int y = t / tiles_x, x0 = (t - y * tiles_x) * TW;
+        uint32_t acc[4] = {uint32_t(lane), 1u, 2u, 3u};
+#pragma unroll
+        for(int j = 0; j < NLOAD; j++)
+        {
+            const int run = (wave + 4 * j) * RPI + lane / LPR; // 0..191 = channel-major: c = run / 64, g = run % 64
+            const int c = run >> 6, g = run & 63;
+            const int sy = min(max(y + offs.oy[g], 0), H - 1);
+            const int start = x0 + offs.ox[g] + padx, k = start & 3;
+            const uint8_t *src = planar + (((size_t)g * 3 + c) * 4 + k) * shift_stride + (size_t)sy * pitch + (start - k) + 16 * (lane % LPR);
+            const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(src);
+            acc[0] ^= v.x; acc[1] ^= v.y; acc[2] ^= v.z; acc[3] ^= v.w;
+        }
+        if(WRITE)
+        {
+            // wave w: views 16w … 16w+15; a lane stores 8 bytes; TW/8 lanes per plane row → 64·8/TW views per instruction
+            constexpr int LPV = TW / 8, VPI = 64 / LPV;
+#pragma unroll
+            for(int i = 0; i < 16 / VPI; i++)
+#pragma unroll
+                for(int ch = 0; ch < 3; ch++)
+                {
+                    const int v = 16 * wave + i * VPI + lane / LPV;
+                    u32x2 *p = reinterpret_cast<u32x2 *>(views + ((size_t)v * 3 + ch) * PLANE + (size_t)y * W + x0 + 8 * (lane % LPV));
+                    const u32x2 val = {acc[0] + i, acc[1] + ch};
+                    __builtin_nontemporal_store(val, p);
+                }
+        }
+        else if((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u)
+            views[t] = 1;
+    }
+}
+
 template <int OUT, bool NT, int MAP>
 __global__ void __launch_bounds__(256) k_tile(const uint8_t *__restrict__ planar, uint8_t *__restrict__ views, const Offs offs, const int pitch, const int padx,
                                               const int tiles_x, const int n_tiles)
@@ -160,6 +205,17 @@ float run(const char *name, int wgs_per_cu, bool quiet = false)
     return ms;
 }
 
+template <int TW, bool WRITE>
+float run_wide(const char *name, int wgs_per_cu)
+{
+    const int tiles_x = W / TW, n_tiles = tiles_x * H; // 1920 = 15·128 = 7.5·256: the ragged half tile is dropped (a bandwidth probe)
+    const int grid = std::min(n_tiles, wgs_per_cu * g_cus);
+    float ms = time_it([&] { hipLaunchKernelGGL((k_wide<TW, WRITE>), dim3(grid), dim3(256), 0, 0, g_planar, g_views, g_o, g_pitch, g_padx, tiles_x, n_tiles); });
+    const double moved = 1.0 * tiles_x * TW * H * (3.0 * NIMG + (WRITE ? 3.0 * NV : 0.0));
+    printf("%-46s wg/cu %d  %8.1f us  %7.0f GB/s moved (%.0f MB)\n", name, wgs_per_cu, ms * 1e3, moved / ms / 1e6, moved / 1e6);
+    return ms;
+}
+
 int main()
 {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
@@ -175,7 +231,17 @@ int main()
     CK(hipMemset(planar, 1, planar_bytes)); CK(hipMemset(g_views, 2, PLANE * 4 * NV));
     g_planar = planar;
     printf("planar copy %.2f GB, pitch %d, padx %d, %d CUs\n", planar_bytes / 1e9, g_pitch, g_padx, g_cus);
-    for(int round = 0; round < 3; round++)
+    for(int round = 0; round < 2; round++)
+        for(int wpc : {2, 4, 8})
+        {
+            run_wide<128, false>("runs 128 B, read only", wpc);
+            run_wide<256, false>("runs 256 B, read only", wpc);
+            run_wide<512, false>("runs 512 B, read only", wpc);
+            run_wide<128, true>("runs 128 B, read + planar write", wpc);
+            run_wide<256, true>("runs 256 B, read + planar write", wpc);
+            run_wide<512, true>("runs 512 B, read + planar write", wpc);
+        }
+    for(int round = 0; round < 1; round++)
     {
         printf("-- round %d\n", round);
         for(int wpc : {2, 4, 8})
