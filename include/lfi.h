@@ -111,7 +111,10 @@ int lfi_set_grid(lfi_ctx *ctx, int cols, int rows, int width, int height);
  * lfi_set_grid: this context renders output rows [out_y0, out_y1) only and holds input rows [in_y0, in_y1) of every image only
  * (band + the halo the warp reaches into); planes shrink accordingly, so G GPUs each read and write ≈1/G of the bytes.  Host
  * pointers passed to upload / download / quilt calls keep addressing row 0 of the WHOLE image; attached device buffers hold
- * the window's rows only.  lfi_set_params verifies that the input rows cover every sampled row.  Fixed-focus renders only. */
+ * the window's rows only.  lfi_set_params verifies that the input rows cover every row a fixed-focus render samples; lfi_focus_map
+ * (which then computes the band's rows of the maps: map 0 for the band plus the filter's reach, map 1 for the band) and all-focus
+ * renders verify their own, larger reach — the warp at both ends of [focus, focus + range], plus the block radius for the map —
+ * and fail with LFI_EINVAL if the held rows fall short (lfinterpolator_amd/sharding.py input_rows_all_focus computes them). */
 int lfi_set_row_window(lfi_ctx *ctx, int out_y0, int out_y1, int in_y0, int in_y1);
 /* cudaMemcpy2DToArray of one image (src/interpolator.cu:91): copies; the caller keeps ownership.  Synchronous. */
 int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_bytes);

@@ -11,9 +11,9 @@ from .abi import (LFI_METHOD_STD, LFI_METHOD_TEN_WM, LFI_FLAG_UNIFIED_FOCUS_MAP,
                   Context, LfiError, load_hip_library, ABI_SYMBOLS)
 from .host import HostParams, build_params, load_host_library, load_image, write_png, load_grid
 from .build import build_all
-from .sharding import view_range, rank_params, broadcast_grid, allgather_grid, image_slice, row_band, input_rows
+from .sharding import view_range, rank_params, broadcast_grid, allgather_grid, image_slice, row_band, input_rows, input_rows_all_focus
 from . import build
 
 __all__ = ["LFI_LAYOUT_RGBA", "LFI_LAYOUT_PLANAR_RGB", "LFI_METHOD_STD", "LFI_METHOD_TEN_WM", "LFI_FLAG_UNIFIED_FOCUS_MAP", "LFI_FLAG_TEN_ROUND_PER_BATCH",
            "Context", "LfiError", "load_hip_library", "ABI_SYMBOLS", "HostParams", "build_params", "load_host_library", "load_image", "write_png", "load_grid",
-           "build_all", "view_range", "rank_params", "broadcast_grid", "allgather_grid", "image_slice", "row_band", "input_rows"]
+           "build_all", "view_range", "rank_params", "broadcast_grid", "allgather_grid", "image_slice", "row_band", "input_rows", "input_rows_all_focus"]

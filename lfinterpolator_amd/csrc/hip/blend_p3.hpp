@@ -167,31 +167,41 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
         if constexpr(ABL == 1)
             return;
         const uint8_t *pb = lds + buf * P3_BUF_B + lane_px;
+        // groups = (k-step, channel): eight ds_read_b64 (the lane's eight pixels of images 8kg … 8kg+7), then eight MFMAs.  The reads
+        // of group i + 1 are issued BEFORE the MFMAs of group i (register double buffer, pinned by a scheduling barrier): left to
+        // itself the compiler issues them one MFMA ahead of their use and every group start waits for LDS (tools/p3_ablate.py: the
+        // k-loop alone was 0.7 of the kernel's time at 15×15 grids).
+        const int n_groups = kc > 32 ? 6 : 3; // wave-uniform: a chunk of ≤ 32 images has one k-step
+        u32x2 d[2][8];
+        auto load_group = [&](const int grp, u32x2 (&dst)[8]) {
+            const int ks = grp / 3, ch = grp - 3 * ks;
 #pragma unroll
-        for(int ks = 0; ks < 2; ks++)
+            for(int j = 0; j < 8; j++)
+                dst[j] = *reinterpret_cast<const u32x2 *>(pb + ch * P3_CH_B + p3_octet_off(4 * ks) + 128 * j);
+        };
+        load_group(0, d[0]);
+#pragma unroll
+        for(int grp = 0; grp < 6; grp++)
         {
-            if(32 * ks >= kc) // wave-uniform
-                continue;
+            if(grp >= n_groups)
+                break;
+            if(grp + 1 < 6 && grp + 1 < n_groups)
+                load_group(grp + 1, d[(grp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ks = grp / 3, ch = grp - 3 * ks;
+            const u32x2(&dc)[8] = d[grp & 1];
 #pragma unroll
-            for(int ch = 0; ch < 3; ch++)
+            for(int b = 0; b < 8; b++)
             {
-                u32x2 d[8];
+                u32x4 bf;
 #pragma unroll
-                for(int j = 0; j < 8; j++)
-                    d[j] = *reinterpret_cast<const u32x2 *>(pb + ch * P3_CH_B + p3_octet_off(4 * ks) + 128 * j);
-#pragma unroll
-                for(int b = 0; b < 8; b++)
+                for(int q = 0; q < 4; q++)
                 {
-                    u32x4 bf;
-#pragma unroll
-                    for(int q = 0; q < 4; q++)
-                    {
-                        const uint32_t lo = b < 4 ? d[2 * q].x : d[2 * q].y, hi = b < 4 ? d[2 * q + 1].x : d[2 * q + 1].y;
-                        // [15:0] = byte (b & 3) of image 2q, [31:16] = the same byte of image 2q + 1: two fp16 subnormals
-                        bf[q] = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | uint32_t(b & 3) | (uint32_t(4 + (b & 3)) << 16));
-                    }
-                    acc[b][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[ks], __builtin_bit_cast(half8, bf), acc[b][ch], 0, 0, 0);
+                    const uint32_t lo = b < 4 ? dc[2 * q].x : dc[2 * q].y, hi = b < 4 ? dc[2 * q + 1].x : dc[2 * q + 1].y;
+                    // [15:0] = byte (b & 3) of image 2q, [31:16] = the same byte of image 2q + 1: two fp16 subnormals
+                    bf[q] = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | uint32_t(b & 3) | (uint32_t(4 + (b & 3)) << 16));
                 }
+                acc[b][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[ks], __builtin_bit_cast(half8, bf), acc[b][ch], 0, 0, 0);
             }
         }
     };

@@ -110,15 +110,15 @@ __global__ void __launch_bounds__(64, WPE) focus_estimate_packed(const KernelArg
     const int lane = threadIdx.x & 63;
     const int W = a.width, H = a.height;
     const int x0 = (blockIdx.x * 64 + lane) * PPL;     // first of this lane's pixels
-    const int y = blockIdx.y;                          // one row per wave
-    if(y >= H)
+    const int y = a.map_y0 + blockIdx.y;               // one row per wave, of the rows asked for (a row window computes a band)
+    if(y >= min(H, a.map_y0 + a.map_rows))
         return; // wave-uniform
     const bool lane_active = x0 < W;
     constexpr int STEPS = 32; // src/kernels.cu:245
     const float step = __fdiv_rn(a.range, static_cast<float>(STEPS - 1));
     const int rx = a.radius_x, ry = a.radius_y;
     const uint32_t *grid32 = reinterpret_cast<const uint32_t *>(a.grid);
-    const size_t plane_px = (size_t)W * (size_t)H;
+    const size_t plane_px = (size_t)W * (size_t)a.in_rows; // the rows this context holds (the host checked that they cover the samples)
     typedef const __attribute__((address_space(4))) float *const_float_ptr;
     typedef const __attribute__((address_space(4))) int32_t *const_int_ptr;
     const const_float_ptr c_offsets = (const_float_ptr)(uintptr_t)a.offsets;
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(64, WPE) focus_estimate_packed(const KernelArg
 #pragma unroll
                 for(int ty = 0; ty < 3; ty++)
                 {
-                    const uint32_t *row = plane + (size_t)clampi(cy + (ty - 1) * ry, 0, H - 1) * W;
+                    const uint32_t *row = plane + (size_t)(clampi(cy + (ty - 1) * ry, 0, H - 1) - a.in_y0) * W; // clamp in the image, index the held rows
 #pragma unroll
                     for(int tx = 0; tx < 3; tx++)
                     {
@@ -453,9 +453,9 @@ __global__ void __launch_bounds__(64, 4) focus_estimate_lds(const KernelArgs a)
 __global__ void __launch_bounds__(256) focus_filter(const KernelArgs a)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = a.map_y0 + blockIdx.y * 4 + (threadIdx.x >> 6); // the rows asked for (a row window filters its band)
     const int W = a.width, H = a.height;
-    if(x >= W || y >= H)
+    if(x >= W || y >= min(H, a.map_y0 + a.map_rows))
         return;
     const int rx = max(a.radius_x / 10, 1), ry = max(a.radius_y / 10, 1); // ≥1: SURVEY.md defect D6
     const uint32_t *map0 = reinterpret_cast<const uint32_t *>(a.maps);

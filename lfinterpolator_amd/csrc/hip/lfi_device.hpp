@@ -40,6 +40,7 @@ struct KernelArgs
     // Row window (spatial multi-GPU sharding): this context holds rows [in_y0, in_y0+in_rows) of every input plane and
     // renders output rows [out_y0, out_y0+out_rows) into planes of out_rows rows.  Whole image: 0, height, 0, height.
     int32_t in_y0, in_rows, out_y0, out_rows;
+    int32_t map_y0, map_rows;               // focus-map kernels: the rows of the maps to compute (whole image: 0, height)
     int32_t n_images;                       // constants[5]
     int32_t k_pad;                          // n_images rounded up to 16
     int32_t v_pad;                          // views rounded up to 64

@@ -90,6 +90,7 @@ struct lfi_ctx
     uint32_t flags = 0;
     float *prequant = nullptr;
     std::vector<lfi_float2> h_focus_offsets; // offsets of the focus_map_ids images (host copy: sizes the padded planes)
+    std::vector<lfi_float2> h_offsets;       // offsets of all images (host copy: row-window coverage checks of all-focus renders)
     // planar copy of the inputs for blend_planar (built on demand; valid while planar_version == grid_version)
     uint8_t *planar = nullptr;
     size_t planar_bytes = 0;
@@ -180,6 +181,8 @@ KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
     a.in_rows = c->in_rows;
     a.out_y0 = c->out_y0;
     a.out_rows = c->out_rows;
+    a.map_y0 = 0;
+    a.map_rows = c->height;
     a.n_images = c->n;
     a.k_pad = c->k_pad;
     a.v_pad = c->v_pad;
@@ -593,12 +596,26 @@ int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a
     }
     if(c->windowed)
     {
-        // a row window is honoured by the persistent fixed-focus kernels only
+        // a row window is honoured by the persistent kernels only
         const bool ten = method == LFI_METHOD_TEN_WM;
         const Variant &v = ten ? kTenVariants[c->ten_variant] : kStdVariants[c->std_variant];
-        if(all_focus || a.prequant || !v.row_window || (c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) ||
-           (ten && v.packed_epilogue && !c->weights_scalable))
-            return fail(c, LFI_EINVAL, "with a row window only fixed-focus renders with the default (persistent) kernels and weights in [0,2) are supported");
+        if(a.prequant || !v.row_window || (c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) || (ten && v.packed_epilogue && !c->weights_scalable))
+            return fail(c, LFI_EINVAL, "with a row window only renders with the default (persistent) kernels and weights in [0,2) are supported");
+        if(all_focus)
+        {
+            // every image row an all-focus render of the band can sample must be held: (int)fma(f, offset.y, y) for f between the
+            // ends of the focus range (the map decodes to focus + m/255·range), y in the band; ±1 for float rounding
+            const float f_lo = std::min(c->focus, c->focus + c->range), f_hi = std::max(c->focus, c->focus + c->range);
+            for(const lfi_float2 &o : c->h_offsets)
+            {
+                const double d_lo = std::min((double)f_lo * o.y, (double)f_hi * o.y), d_hi = std::max((double)f_lo * o.y, (double)f_hi * o.y);
+                const int H = c->height;
+                const int lo = std::min(std::max((int)std::floor(c->out_y0 + d_lo) - 1, 0), H - 1);
+                const int hi = std::min(std::max((int)std::ceil(c->out_y0 + c->out_rows - 1 + d_hi) + 1, 0), H - 1);
+                if(lo < c->in_y0 || hi >= c->in_y0 + c->in_rows)
+                    return fail(c, LFI_EINVAL, "the input row window does not cover the rows an all-focus render of this band samples");
+            }
+        }
     }
     if(method == LFI_METHOD_TEN_WM)
     {
@@ -1309,6 +1326,7 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     ctx->v_pad = v_pad;
     ctx->views_n = V;
     ctx->n_focus_ids = p->n_focus_ids;
+    ctx->h_offsets.assign(p->offsets, p->offsets + n);
     ctx->h_focus_offsets.clear();
     for(int k = 0; k < p->n_focus_ids; k++)
         ctx->h_focus_offsets.push_back(p->offsets[p->focus_map_ids[k]]);
@@ -1419,15 +1437,38 @@ int lfi_focus_map(lfi_ctx *ctx)
         return LFI_EINVAL;
     if(!ctx->grid || !ctx->have_params)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid / lfi_set_params have not been called");
-    if(ctx->windowed)
-        return fail(ctx, LFI_EINVAL, "the focus map is not supported with a row window");
     if(ctx->n_focus_ids < 1)
         return fail(ctx, LFI_EINVAL, "no focus_map_ids in the parameters");
     if(!(ctx->range > 0.0f))
         return fail(ctx, LFI_EINVAL, "focus range must be > 0 for the focus map");
     if(int rc = bind(ctx))
         return rc;
-    const KernelArgs a = make_args(ctx, 0, ctx->views_n, LFI_METHOD_STD);
+    KernelArgs a = make_args(ctx, 0, ctx->views_n, LFI_METHOD_STD);
+    if(ctx->windowed)
+    {
+        // Row window (spatial sharding): the maps are whole-image planes, but only the band's rows are computed — map 0 for the band
+        // plus the filter's reach above and below, map 1 for the band — by the one-wave-per-row kernel from the input rows held.
+        const int H = ctx->height, fry = std::max(ctx->radius[1] / 10, 1), ry = ctx->radius[1];
+        const int e0 = std::max(ctx->out_y0 - fry, 0), e1 = std::min(ctx->out_y0 + ctx->out_rows + fry, H);
+        const float f_lo = std::min(ctx->focus, ctx->focus + ctx->range), f_hi = std::max(ctx->focus, ctx->focus + ctx->range);
+        for(const lfi_float2 &o : ctx->h_focus_offsets)
+        {
+            const double d_lo = std::min((double)f_lo * o.y, (double)f_hi * o.y), d_hi = std::max((double)f_lo * o.y, (double)f_hi * o.y);
+            const int lo = std::min(std::max((int)std::floor(e0 + d_lo) - 1 - ry, 0), H - 1);
+            const int hi = std::min(std::max((int)std::ceil(e1 - 1 + d_hi) + 1 + ry, 0), H - 1);
+            if(lo < ctx->in_y0 || hi >= ctx->in_y0 + ctx->in_rows)
+                return fail(ctx, LFI_EINVAL, "the input row window does not cover the rows the focus map of this band samples");
+        }
+        a.map_y0 = e0;
+        a.map_rows = e1 - e0;
+        hipLaunchKernelGGL((lfi::focus_estimate_packed<2, 4>), dim3((ctx->width + 127) / 128, a.map_rows), dim3(64), 0, ctx->stream, a);
+        LFI_HIP(ctx, hipGetLastError());
+        a.map_y0 = ctx->out_y0;
+        a.map_rows = ctx->out_rows;
+        hipLaunchKernelGGL(lfi::focus_filter, dim3((ctx->width + 63) / 64, (ctx->out_rows + 3) / 4), dim3(256), 0, ctx->stream, a);
+        LFI_HIP(ctx, hipGetLastError());
+        return LFI_OK;
+    }
     // the LDS-staged kernel needs its window (128 + 2·radius_x + slack pixels) to fit a 256-pixel LDS row
     const bool lds_fits = 128 + 2 * ctx->radius[0] + 2 * lfi::FOCUS_LDS_SLACK <= lfi::FOCUS_LDS_ROW;
     // "factored" (default): W and H must fit the 16-bit column / row lists

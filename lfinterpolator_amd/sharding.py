@@ -70,3 +70,26 @@ def input_rows(band: tuple[int, int], focused_offsets, height: int) -> tuple[int
     lo = np.clip(band[0] + oy, 0, height - 1).min()
     hi = np.clip(band[1] - 1 + oy, 0, height - 1).max()
     return int(lo), int(hi) + 1
+
+
+def input_rows_all_focus(band: tuple[int, int], offsets, focus_map_ids, focus: float, range_: float, block_radius, height: int) -> tuple[int, int]:
+    """Rows [in_y0, in_y1) a rank must hold to compute ITS BAND of the focus maps and to render the band all-focused: the
+    per-pixel warp (int)fma(f, offset.y, y) at both ends of [focus, focus + range] for every image (render) and, for the images
+    the estimate samples, from the band extended by the filter's reach, plus / minus the block radius (the 3×3 taps) — the same
+    conservative bounds (±1 for float rounding) the library checks."""
+    import math
+    import numpy as np
+    off_y = np.asarray(offsets, dtype=np.float64)[:, 1]
+    f_lo, f_hi = min(focus, focus + range_), max(focus, focus + range_)
+    d_lo = np.minimum(f_lo * off_y, f_hi * off_y)
+    d_hi = np.maximum(f_lo * off_y, f_hi * off_y)
+    lo = math.floor(band[0] + d_lo.min()) - 1
+    hi = math.ceil(band[1] - 1 + d_hi.max()) + 1
+    ry = int(block_radius[1])
+    fry = max(ry // 10, 1)
+    e0, e1 = max(band[0] - fry, 0), min(band[1] + fry, height)
+    ids = np.asarray(focus_map_ids, dtype=np.int64)
+    if len(ids):
+        lo = min(lo, math.floor(e0 + d_lo[ids].min()) - 1 - ry)
+        hi = max(hi, math.ceil(e1 - 1 + d_hi[ids].max()) + 1 + ry)
+    return max(min(lo, height - 1), 0), min(max(hi, 0), height - 1) + 1

@@ -277,11 +277,6 @@ def test_row_band_sharding_matches_full_render(world, gpu, oracle_c):
             part = ctx.download_views()
             assert (part[:, :band[0]] == 0).all() and (part[:, band[1]:] == 0).all()
             got |= part
-            if rank == 0:
-                with pytest.raises(gpu.LfiError, match="row window"):
-                    ctx.render(method, all_focus=True)
-                with pytest.raises(gpu.LfiError, match="row window"):
-                    ctx.focus_map()
             ctx.close()
         assert (got == want).all(), method
         assert max(held) < H
@@ -632,4 +627,65 @@ def test_std_near_half_integer_sums_from_precise_weights(gpu, oracle_c):
     ctx.set_variant("STD", "auto")
     ctx.render("STD")
     assert ctx.last_kernel_name() == "blend_planar<STDF>"
+    ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_band_sharding_all_focus(world, gpu, oracle_c):
+    """SURVEY.md §8(f).2 for the all-focus path (BASELINE config 5 sharded by rows): every rank computes ITS BAND of the focus maps
+    from the input rows it holds (band + the warp's reach over the focus range + the block radius) and renders the band
+    all-focused; maps and views reassemble to the single-GPU result byte for byte.  Too few input rows are refused."""
+    cols = rows = 8
+    W, H, V = 160, 120, 8
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.05, 0.12, 7.0, 1.783, V)
+    lf = oracle_c.synthetic_lf(64, W, H, SEED)
+    full = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    full.focus_map()
+    full.sync()
+    want_maps = (full.download_map(0), full.download_map(1))
+    want = {}
+    for method in ("STD", "TEN_WM"):
+        full.render(method, all_focus=True)
+        full.sync()
+        want[method] = full.download_views()
+    full.close()
+    got = {m: np.zeros_like(want[m]) for m in want}
+    got_map1 = np.zeros_like(want_maps[1])
+    held = []
+    for rank in range(world):
+        band = gpu.row_band(H, world, rank)
+        in_rows = gpu.input_rows_all_focus(band, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, H)
+        held.append(in_rows[1] - in_rows[0])
+        ctx = gpu.Context(0)
+        ctx.set_grid(cols, rows, W, H)
+        ctx.set_row_window(band[0], band[1], in_rows[0], in_rows[1])
+        ctx.upload_grid(lf)
+        ctx.set_params(hp)
+        ctx.focus_map()
+        ctx.sync()
+        m0, m1 = ctx.download_map(0), ctx.download_map(1)
+        assert (m0[band[0]:band[1]] == want_maps[0][band[0]:band[1]]).all()
+        assert (m1[band[0]:band[1]] == want_maps[1][band[0]:band[1]]).all()
+        got_map1[band[0]:band[1]] = m1[band[0]:band[1]]
+        for method in ("STD", "TEN_WM"):
+            ctx.render(method, all_focus=True)
+            ctx.sync()
+            got[method] |= ctx.download_views()
+        ctx.close()
+    assert (got_map1 == want_maps[1]).all()
+    for method in want:
+        assert (got[method] == want[method]).all(), method
+    assert max(held) < H or world == 2
+    # a window that covers the fixed-focus reach only is refused by the all-focus paths
+    band = gpu.row_band(H, 3, 1)
+    small = gpu.input_rows(band, hp.focused_offsets, H)
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.set_row_window(band[0], band[1], small[0], small[1])
+    ctx.fill_synthetic(SEED)
+    ctx.set_params(hp)
+    with pytest.raises(gpu.LfiError, match="does not cover"):
+        ctx.focus_map()
+    with pytest.raises(gpu.LfiError, match="does not cover"):
+        ctx.render("TEN_WM", all_focus=True)
     ctx.close()
