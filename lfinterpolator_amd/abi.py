@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
     "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
-    "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_fill_synthetic_scene", "lfi_debug_mfma_f16_chain",
+    "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_fill_synthetic_scene", "lfi_upload_image_async", "lfi_upload_wait", "lfi_debug_mfma_f16_chain",
 ]
 
 
@@ -114,6 +114,8 @@ def load_hip_library() -> C.CDLL:
         "lfi_download_prequant": (i, [vp, i, i, i, vp]),
         "lfi_debug_mfma_f16": (i, [vp, vp, vp, vp]),
         "lfi_prepare": (i, [vp, i, i, i, i]),
+        "lfi_upload_image_async": (i, [vp, i, vp, sz]),
+        "lfi_upload_wait": (i, [vp]),
         "lfi_fill_synthetic_scene": (i, [vp, C.c_uint32, C.c_float, C.c_float]),
         "lfi_debug_mfma_f16_chain": (i, [vp, i, i, vp, vp, vp]),
         "lfi_set_output_layout": (i, [vp, i]),
@@ -203,11 +205,23 @@ class Context:
         assert rgba.shape == (self.height, self.width, 4)
         self._check(self._lib.lfi_upload_image(self._h, g, _ptr(rgba), self.width * 4))
 
-    def upload_grid(self, lf: np.ndarray) -> None:
+    def upload_grid(self, lf: np.ndarray, asynchronous: bool = False) -> None:
         """lf: [N][H][W][4] u8 with g = col*rows + row."""
         assert lf.shape == (self.n_images, self.height, self.width, 4)
         for g in range(self.n_images):
-            self.upload_image(g, lf[g])
+            if asynchronous:
+                self.upload_image_async(g, lf[g])
+            else:
+                self.upload_image(g, lf[g])
+
+    def upload_image_async(self, g: int, rgba: np.ndarray) -> None:
+        """Enqueue the copy on the context's copy stream; `rgba` may be pageable (staged, free on return) or from pinned_empty
+        (DMA'd in place: keep it alive until upload_wait / sync)."""
+        assert rgba.shape == (self.height, self.width, 4) and rgba.dtype == np.uint8 and rgba.flags.c_contiguous
+        self._check(self._lib.lfi_upload_image_async(self._h, g, _ptr(rgba), self.width * 4))
+
+    def upload_wait(self) -> None:
+        self._check(self._lib.lfi_upload_wait(self._h))
 
     def attach_grid(self, device_ptr: int, nbytes: int) -> None:
         self._check(self._lib.lfi_attach_grid(self._h, C.c_void_p(device_ptr), nbytes))

@@ -30,6 +30,8 @@
 // Replaces Kernels::Tensors::process<false> (reference src/kernels.cu:398-461).
 #pragma once
 
+#include <type_traits>
+
 #include "blend_planar.hpp"
 
 namespace lfi {
@@ -140,7 +142,9 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
             const int sy = clampi(y + pc.oy[o2], 0, H - 1) - a.in_y0; // clamp in the full image, then index the held rows
             const int start = x0 + pc.ox[o2] + a.planar_padx;
             const int k = start & 3;
-            const uint8_t *src = a.planar + pc.plane0[o2] + ((size_t)k * a.in_rows + sy) * a.planar_pitch + (start - k) + 16 * (lane & 7);
+            // (k·rows + sy)·pitch with full-rate 24-bit multiplies (rows, pitch < 2^24; the product < 2^32: checked on the host)
+            const uint32_t row_off = __umul24(__umul24(uint32_t(k), uint32_t(a.in_rows)) + uint32_t(sy), uint32_t(a.planar_pitch));
+            const uint8_t *src = a.planar + pc.plane0[o2] + row_off + (start - k) + 16 * (lane & 7);
             if constexpr(ABL != 2)
             {
 #pragma unroll
@@ -163,9 +167,12 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
 
     // k-loop of one unit from buffer `buf`: wk = the chunk's two weight fragments
     const uint32_t lane_px = uint32_t(1024 * kg + 128 * ((kg + 1) >> 1) + 8 * n); // p3_octet_off(kg) + this lane's 8 pixels
-    auto compute = [&](const half8 (&wk)[2], const int buf, const int kc) {
+    // `fresh` (one-chunk launches): the first k-step takes a zero C operand, so the accumulators are never cleared
+    auto compute = [&](const half8 (&wk)[2], const int buf, const int kc, auto fresh_tag) {
+        constexpr bool fresh = decltype(fresh_tag)::value;
         if constexpr(ABL == 1)
             return;
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
         const uint8_t *pb = lds + buf * P3_BUF_B + lane_px;
         // groups = (k-step, channel): eight ds_read_b64 (the lane's eight pixels of images 8kg … 8kg+7), then eight MFMAs.  The reads
         // of group i + 1 are issued BEFORE the MFMAs of group i (register double buffer, pinned by a scheduling barrier): left to
@@ -201,13 +208,13 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
                     // [15:0] = byte (b & 3) of image 2q, [31:16] = the same byte of image 2q + 1: two fp16 subnormals
                     bf[q] = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | uint32_t(b & 3) | (uint32_t(4 + (b & 3)) << 16));
                 }
-                acc[b][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[ks], __builtin_bit_cast(half8, bf), acc[b][ch], 0, 0, 0);
+                acc[b][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[ks], __builtin_bit_cast(half8, bf), (ks == 0 && fresh) ? zero4 : acc[b][ch], 0, 0, 0);
             }
         }
     };
 
     // epilogue of tile t: quantise (acc = S·2^-9), pack eight pixels per (view, channel), store; returns the number of store
-    // instructions issued (wave-uniform); clears acc
+    // instructions issued (wave-uniform)
     const uint32_t plane_b = uint32_t(a.out_rows) * uint32_t(a.views_pitch); // bytes of one byte plane (< 2^26·… checked on the host)
     auto epilogue = [&](const int t, const int vw, const int nvalid) {
         const int ty = t / tiles_x; // row inside the output window
@@ -273,11 +280,6 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
                 }
             }
         }
-#pragma unroll
-        for(int b = 0; b < 8; b++)
-#pragma unroll
-            for(int ch = 0; ch < 3; ch++)
-                acc[b][ch] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         return n_st;
     };
 
@@ -352,7 +354,7 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
                 if(nvalid > 0)
                 {
                     const half8 wk[2] = {wreg[0], wreg[1]};
-                    compute(wk, buf, kc);
+                    compute(wk, buf, kc, std::true_type{});
                     st1 += epilogue(ct, vw, nvalid);
                 }
                 if(view_passes > 1)
@@ -377,9 +379,16 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
                         wk[0] = wreg[2 * c];
                         wk[1] = wreg[2 * c + 1];
                     }
-                compute(wk, buf, kc);
+                compute(wk, buf, kc, std::false_type{}); // (a second, zero-C copy of the k-loop for chunk 0 costs more registers than the clear)
                 if(cc == NCH - 1)
+                {
                     st1 = epilogue(ct, vw0, nvalid);
+#pragma unroll
+                    for(int b = 0; b < 8; b++)
+#pragma unroll
+                        for(int ch = 0; ch < 3; ch++)
+                            acc[b][ch] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
             }
         }
         if(!have1)

@@ -14,6 +14,8 @@
 //                      B = pixels (lane l: pixel l&31, image l>>5), so the image pair of one MFMA is (2q, 2q+1) in order.
 #pragma once
 
+#include <type_traits>
+
 #include "blend_ten.hpp"
 #include "lfi_device.hpp"
 
@@ -123,17 +125,36 @@ __global__ void __launch_bounds__(256, 2) blend_std_vfma(const KernelArgs a)
     float focus_px = 0.0f;
     if constexpr(ALLFOCUS)
         focus_px = decode_focus(a.maps + (size_t)a.map_index * plane_px * 4, W, H, xc, y, a.focus, a.range);
-    auto fetch = [&](const int g) {
-        int sx, sy;
+    // per-image offsets (integer, or float for the all-focus warp) as two dwords, read one stage ahead of the fetch that uses them
+    struct Off2
+    {
+        uint32_t x, y;
+    };
+    auto load_off = [&](const int g) {
+        Off2 o;
         if constexpr(ALLFOCUS)
         {
-            sx = warp_float(xc, focus_px, c_offsets[2 * g]);
-            sy = warp_float(y, focus_px, c_offsets[2 * g + 1]);
+            o.x = __builtin_bit_cast(uint32_t, c_offsets[2 * g]);
+            o.y = __builtin_bit_cast(uint32_t, c_offsets[2 * g + 1]);
         }
         else
         {
-            sx = xc + c_focused[2 * g];
-            sy = y + c_focused[2 * g + 1];
+            o.x = uint32_t(c_focused[2 * g]);
+            o.y = uint32_t(c_focused[2 * g + 1]);
+        }
+        return o;
+    };
+    auto fetch = [&](const int g, const Off2 o) {
+        int sx, sy;
+        if constexpr(ALLFOCUS)
+        {
+            sx = warp_float(xc, focus_px, __builtin_bit_cast(float, o.x));
+            sy = warp_float(y, focus_px, __builtin_bit_cast(float, o.y));
+        }
+        else
+        {
+            sx = xc + int(o.x);
+            sy = y + int(o.y);
         }
         return grid32[(size_t)g * plane_px + (size_t)clampi(sy, 0, H - 1) * W + clampi(sx, 0, W - 1)];
     };
@@ -146,23 +167,61 @@ __global__ void __launch_bounds__(256, 2) blend_std_vfma(const KernelArgs a)
 #pragma unroll
             for(int c = 0; c < 3; c++)
                 acc[j][c] = float2v{0.0f, 0.0f};
-        uint32_t p0 = fetch(0), p1 = fetch(min(1, n - 1));
-        for(int g = 0; g < n; g++) // ascending g: src/kernels.cu:328
-        {
-            const uint32_t p2 = fetch(min(g + 2, n - 1));
-            const float pr = static_cast<float>(p0 & 0xffu), pg = static_cast<float>((p0 >> 8) & 0xffu), pb = static_cast<float>((p0 >> 16) & 0xffu);
-            const float2v r2 = {pr, pr}, g2 = {pg, pg}, b2 = {pb, pb};
-            const const_float_ptr wrow = c_w32t + (size_t)g * a.v_pad + vb; // rows are padded to 64 + 64 views
+        // Weights: 32 per stage (two s_load_dwordx16) into one of two SGPR sets; a stage first makes sure ITS set has arrived, then
+        // issues the loads of the next stage's set, then runs its 48 v_pk_fma_f32 — scalar loads return out of order, so the only
+        // wait there is is lgkmcnt(0), and it has to sit BEFORE the next loads are issued for their latency to hide under the FMAs.
+        auto load32 = [&](const int g, const int half, float (&w)[32]) {
+            const const_float_ptr wrow = c_w32t + (size_t)g * a.v_pad + vb + 32 * half; // rows are padded to 64 + 64 views
 #pragma unroll
-            for(int j = 0; j < 32; j++)
+            for(int i = 0; i < 32; i++)
+                w[i] = wrow[i];
+        };
+        auto arrived = [&](const float (&w)[32]) { asm volatile("" ::"s"(w[0]), "s"(w[16])); };
+        auto fma32 = [&](auto half_tag, const float (&w)[32], const float2v r2, const float2v g2, const float2v b2) {
+            constexpr int HALF = decltype(half_tag)::value;
+#pragma unroll
+            for(int j = 0; j < 16; j++)
             {
-                const float2v w2 = {wrow[2 * j], wrow[2 * j + 1]};
-                acc[j][0] = __builtin_elementwise_fma(r2, w2, acc[j][0]);
-                acc[j][1] = __builtin_elementwise_fma(g2, w2, acc[j][1]);
-                acc[j][2] = __builtin_elementwise_fma(b2, w2, acc[j][2]);
+                const float2v w2 = {w[2 * j], w[2 * j + 1]};
+                acc[16 * HALF + j][0] = __builtin_elementwise_fma(r2, w2, acc[16 * HALF + j][0]);
+                acc[16 * HALF + j][1] = __builtin_elementwise_fma(g2, w2, acc[16 * HALF + j][1]);
+                acc[16 * HALF + j][2] = __builtin_elementwise_fma(b2, w2, acc[16 * HALF + j][2]);
             }
-            p0 = p1;
-            p1 = p2;
+        };
+        // Pixels: a ring of four registers, image g + 3 is fetched while image g is accumulated (no register moves: the loop is
+        // unrolled by four).  Scalar loads (weights, offsets) are issued only right after a stage's lgkmcnt(0), so each has a whole
+        // stage of FMAs to arrive.
+        float wA[32], wB[32];
+        load32(0, 0, wA);
+        uint32_t px[4];
+#pragma unroll
+        for(int u = 0; u < 3; u++)
+            px[u] = fetch(min(u, n - 1), load_off(min(u, n - 1)));
+        Off2 off_next = load_off(min(3, n - 1));
+        for(int g0 = 0; g0 < n; g0 += 4) // ascending g: src/kernels.cu:328
+        {
+#pragma unroll
+            for(int u = 0; u < 4; u++)
+            {
+                const int g = g0 + u;
+                if(g >= n) // wave-uniform
+                    break;
+                arrived(wA); // … and off_next
+                px[(u + 3) & 3] = fetch(min(g + 3, n - 1), off_next);
+                load32(g, 1, wB);
+                off_next = load_off(min(g + 4, n - 1));
+                const uint32_t p0 = px[u];
+                const float pr = static_cast<float>(p0 & 0xffu), pg = static_cast<float>((p0 >> 8) & 0xffu), pb = static_cast<float>((p0 >> 16) & 0xffu);
+                const float2v r2 = {pr, pr}, g2 = {pg, pg}, b2 = {pb, pb};
+                __builtin_amdgcn_sched_barrier(0);
+                fma32(std::integral_constant<int, 0>{}, wA, r2, g2, b2);
+                __builtin_amdgcn_sched_barrier(0);
+                arrived(wB);
+                load32(min(g + 1, n - 1), 0, wA);
+                __builtin_amdgcn_sched_barrier(0);
+                fma32(std::integral_constant<int, 1>{}, wB, r2, g2, b2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         uint32_t *out = reinterpret_cast<uint32_t *>(a.views) + (size_t)vb * plane_px + (size_t)y * W + x;
 #pragma unroll

@@ -54,6 +54,16 @@ struct lfi_ctx
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_order = nullptr; // orders the work of the stream a caller switches away from before the stream it switches to
+    // asynchronous uploads (lfi_upload_image_async): a copy stream, a ring of page-locked staging slots for pageable sources
+    static constexpr int kUploadSlots = 4;
+    hipStream_t copy_stream = nullptr;
+    uint8_t *upload_slot[kUploadSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t upload_done[kUploadSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool upload_slot_used[kUploadSlots] = {false, false, false, false};
+    size_t upload_slot_bytes = 0;
+    int upload_next = 0;
+    bool uploads_pending = false; // copies enqueued on copy_stream that the compute stream has not been ordered after yet
+    hipEvent_t ev_uploads = nullptr;
     // side stream of the factored focus-map estimate (its small passes overlap the large ones), created on first use
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_pad = nullptr, ev_join = nullptr;
@@ -129,6 +139,29 @@ int bind(lfi_ctx *ctx)
 {
     LFI_HIP(ctx, hipSetDevice(ctx->device));
     return LFI_OK;
+}
+
+// Order everything enqueued on the compute stream from now on after the asynchronous uploads issued so far (no host wait).
+int join_uploads(lfi_ctx *c)
+{
+    if(!c->uploads_pending)
+        return LFI_OK;
+    LFI_HIP(c, hipEventRecord(c->ev_uploads, c->copy_stream));
+    LFI_HIP(c, hipStreamWaitEvent(c->stream, c->ev_uploads, 0));
+    c->uploads_pending = false;
+    return LFI_OK;
+}
+
+void free_upload_ring(lfi_ctx *c)
+{
+    for(int i = 0; i < lfi_ctx::kUploadSlots; i++)
+    {
+        if(c->upload_slot[i])
+            (void)hipHostFree(c->upload_slot[i]);
+        c->upload_slot[i] = nullptr;
+        c->upload_slot_used[i] = false;
+    }
+    c->upload_slot_bytes = 0;
 }
 
 size_t plane_bytes(const lfi_ctx *c) // a whole-image plane (focus maps; inputs and outputs without a row window)
@@ -449,6 +482,9 @@ bool ensure_planar(lfi_ctx *c)
         return true;
     const int padx = std::max(need, c->planar_padx);
     const int pitch = (c->width + 2 * padx + 15) / 16 * 16;
+    // blend_p3 addresses a row as (shift·rows + row)·pitch with 24-bit multiplies and a 32-bit product
+    if(c->in_rows >= (1 << 22) || pitch >= (1 << 24) || (uint64_t)4 * c->in_rows * pitch >= (1ull << 32))
+        return false;
     const size_t bytes = (size_t)c->n * 12 * c->in_rows * pitch; // the rows this context holds (a row window: band + halo)
     if(bytes != c->planar_bytes)
     {
@@ -549,6 +585,8 @@ int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a
 
 int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
 {
+    if(int rc = join_uploads(c))
+        return rc;
     if(c->out_layout != LFI_LAYOUT_PLANAR_RGB)
         return launch_blend_rgba(c, method, all_focus, a_in);
     if(wants_p3(c, method, all_focus, a_in) && ensure_planar(c))
@@ -958,6 +996,17 @@ int lfi_destroy(lfi_ctx *ctx)
         (void)hipEventDestroy(ctx->ev1);
     if(ctx->ev_order)
         (void)hipEventDestroy(ctx->ev_order);
+    if(ctx->copy_stream)
+    {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    free_upload_ring(ctx);
+    for(int i = 0; i < lfi_ctx::kUploadSlots; i++)
+        if(ctx->upload_done[i])
+            (void)hipEventDestroy(ctx->upload_done[i]);
+    if(ctx->ev_uploads)
+        (void)hipEventDestroy(ctx->ev_uploads);
     if(ctx->ev_fork)
         (void)hipEventDestroy(ctx->ev_fork);
     if(ctx->ev_pad)
@@ -1002,6 +1051,8 @@ int lfi_set_grid(lfi_ctx *ctx, int cols, int rows, int width, int height)
         return fail(ctx, LFI_EINVAL, "image too large");
     if(int rc = bind(ctx))
         return rc;
+    if(int rc = lfi_upload_wait(ctx))
+        return rc;
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_params(ctx);
     free_views(ctx);
@@ -1035,6 +1086,8 @@ int lfi_set_row_window(lfi_ctx *ctx, int out_y0, int out_y1, int in_y0, int in_y
         return fail(ctx, LFI_EINVAL, "row window outside the image");
     if(int rc = bind(ctx))
         return rc;
+    if(int rc = lfi_upload_wait(ctx))
+        return rc;
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_params(ctx);
     free_views(ctx);
@@ -1065,11 +1118,84 @@ int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_byte
         return fail(ctx, LFI_EINVAL, "bad image index, pointer or pitch");
     if(int rc = bind(ctx))
         return rc;
+    if(int rc = join_uploads(ctx))
+        return rc;
     // rgba addresses row 0 of the whole image; only the rows this context holds are copied
     LFI_HIP(ctx, hipMemcpy2DAsync(ctx->grid + in_plane_bytes(ctx) * g, (size_t)ctx->width * 4, rgba + (size_t)ctx->in_y0 * pitch_bytes,
                                   pitch_bytes, (size_t)ctx->width * 4, ctx->in_rows, hipMemcpyHostToDevice, ctx->stream));
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->grid_version++;
+    return LFI_OK;
+}
+
+int lfi_upload_image_async(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_bytes)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(!ctx->grid)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(g < 0 || g >= ctx->n || !rgba || pitch_bytes < (size_t)ctx->width * 4)
+        return fail(ctx, LFI_EINVAL, "bad image index, pointer or pitch");
+    if(int rc = bind(ctx))
+        return rc;
+    if(!ctx->copy_stream)
+    {
+        LFI_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_uploads, hipEventDisableTiming));
+        for(int i = 0; i < lfi_ctx::kUploadSlots; i++)
+            LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->upload_done[i], hipEventDisableTiming));
+    }
+    if(!ctx->uploads_pending)
+    {
+        // first copy of a batch: renders already enqueued on the compute stream may still read the planes
+        LFI_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
+        LFI_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_order, 0));
+    }
+    const size_t row_bytes = (size_t)ctx->width * 4;
+    const uint8_t *src = rgba + (size_t)ctx->in_y0 * pitch_bytes; // rgba addresses row 0 of the whole image; the held rows are copied
+    size_t src_pitch = pitch_bytes;
+    hipPointerAttribute_t attr{};
+    const bool page_locked = hipPointerGetAttributes(&attr, rgba) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if(!page_locked)
+    {
+        (void)hipGetLastError(); // pageable memory is "invalid value" to the query
+        // pageable source: stage it through a page-locked slot (the call has copy semantics: the caller's buffer is free on return)
+        const size_t need = row_bytes * ctx->in_rows;
+        if(ctx->upload_slot_bytes != need)
+        {
+            LFI_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+            free_upload_ring(ctx);
+            for(int i = 0; i < lfi_ctx::kUploadSlots; i++)
+                LFI_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->upload_slot[i]), need, hipHostMallocDefault));
+            ctx->upload_slot_bytes = need;
+        }
+        const int slot = ctx->upload_next++ % lfi_ctx::kUploadSlots;
+        if(ctx->upload_slot_used[slot])
+            LFI_HIP(ctx, hipEventSynchronize(ctx->upload_done[slot])); // its previous copy has left the slot
+        for(int y = 0; y < ctx->in_rows; y++)
+            std::memcpy(ctx->upload_slot[slot] + (size_t)y * row_bytes, src + (size_t)y * pitch_bytes, row_bytes);
+        LFI_HIP(ctx, hipMemcpyAsync(ctx->grid + in_plane_bytes(ctx) * g, ctx->upload_slot[slot], need, hipMemcpyHostToDevice, ctx->copy_stream));
+        LFI_HIP(ctx, hipEventRecord(ctx->upload_done[slot], ctx->copy_stream));
+        ctx->upload_slot_used[slot] = true;
+    }
+    else
+        LFI_HIP(ctx, hipMemcpy2DAsync(ctx->grid + in_plane_bytes(ctx) * g, row_bytes, src, src_pitch, row_bytes, ctx->in_rows, hipMemcpyHostToDevice,
+                                      ctx->copy_stream));
+    ctx->uploads_pending = true;
+    ctx->grid_version++;
+    return LFI_OK;
+}
+
+int lfi_upload_wait(lfi_ctx *ctx)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(int rc = bind(ctx))
+        return rc;
+    if(int rc = join_uploads(ctx))
+        return rc;
+    if(ctx->copy_stream)
+        LFI_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     return LFI_OK;
 }
 
@@ -1084,6 +1210,8 @@ int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes)
     if(reinterpret_cast<uintptr_t>(device_ptr) % 16)
         return fail(ctx, LFI_EINVAL, "attached grid buffer must be 16-byte aligned");
     if(int rc = bind(ctx))
+        return rc;
+    if(int rc = lfi_upload_wait(ctx))
         return rc;
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if(ctx->own_grid && ctx->grid)
@@ -1122,6 +1250,10 @@ int lfi_broadcast_grid(lfi_ctx *const *ctxs, int n, int root)
     const Rccl &nc = rccl();
     if(!nc.ok)
         return fail(r0, LFI_EHIP, "librccl.so could not be loaded");
+    for(int i = 0; i < n; i++)
+        if(ctxs[i]->uploads_pending)
+            if(int rc = lfi_upload_wait(ctxs[i]))
+                return rc;
     int caller_device = -1; // the loop below walks the contexts' devices; the caller's current device is restored afterwards
     (void)hipGetDevice(&caller_device);
     std::vector<Rccl::comm_t> comms(n, nullptr);
@@ -1168,6 +1300,8 @@ int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes)
 {
     if(!ctx || !out_ptr)
         return LFI_EINVAL;
+    if(ctx->uploads_pending && bind(ctx) == LFI_OK)
+        (void)lfi_upload_wait(ctx); // the caller is about to read or write the planes itself
     *out_ptr = ctx->grid;
     if(out_bytes)
         *out_bytes = ctx->grid ? in_plane_bytes(ctx) * ctx->n : 0;
@@ -1198,6 +1332,8 @@ int lfi_fill_synthetic_images(lfi_ctx *ctx, uint32_t seed, int g0, int g1)
     if(g0 == g1)
         return LFI_OK;
     if(int rc = bind(ctx))
+        return rc;
+    if(int rc = join_uploads(ctx))
         return rc;
     ctx->grid_version++;
     hipLaunchKernelGGL(lfi::fill_synthetic, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, g0, g1 - g0, ctx->width,
@@ -1443,6 +1579,8 @@ int lfi_focus_map(lfi_ctx *ctx)
         return fail(ctx, LFI_EINVAL, "focus range must be > 0 for the focus map");
     if(int rc = bind(ctx))
         return rc;
+    if(int rc = join_uploads(ctx))
+        return rc;
     KernelArgs a = make_args(ctx, 0, ctx->views_n, LFI_METHOD_STD);
     if(ctx->windowed)
     {
@@ -1508,6 +1646,8 @@ int lfi_prepare(lfi_ctx *ctx, int method, int all_focus, int v0, int v1)
         return rc;
     if(int rc = bind(ctx))
         return rc;
+    if(int rc = join_uploads(ctx))
+        return rc;
     const KernelArgs a = make_args(ctx, v0, v1, method);
     ctx->derived_build_ms = 0.0f;
     if(wants_planar(ctx, method, all_focus, a))
@@ -1546,6 +1686,8 @@ int lfi_sync(lfi_ctx *ctx)
     if(!ctx)
         return LFI_EINVAL;
     if(int rc = bind(ctx))
+        return rc;
+    if(int rc = join_uploads(ctx))
         return rc;
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LFI_OK;

@@ -106,9 +106,12 @@ void Interpolator::loadGPUData()
         for(int row = 0; row < colsRows.y; row++)
         {
             // image id = col*rows + row, the order the reference creates its surfaces in (src/interpolator.cu:106-113)
-            check(lfi_upload_image(context, col * colsRows.y + row, lfLoader.image({col, row}).data(), static_cast<size_t>(resolution.x) * channels));
+            // asynchronous: staged through page-locked slots on the library's copy stream, so the host walks on to the next image
+            // while this one crosses PCIe (the reference copies synchronously: src/interpolator.cu:85-93, 106-113)
+            check(lfi_upload_image_async(context, col * colsRows.y + row, lfLoader.image({col, row}).data(), static_cast<size_t>(resolution.x) * channels));
             bar.add();
         }
+    check(lfi_upload_wait(context));
 }
 
 void Interpolator::interpolate(std::string outputPath, std::string trajectory, float inFocus, float inRange, std::string method, float effect, float aspect)

@@ -65,3 +65,67 @@ def test_product_never_touches_the_oracle():
                         if re.search(r'#include\s+"[^"]*oracle|import\s+oracle|from\s+oracle|lfo_[a-z0-9_]+\s*\(', text):
                             bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def _gfx950_code_object(native, tmp_path):
+    """The gfx950 ELF inside the shared library's clang offload bundle."""
+    import struct
+    data = open(native.build.HIP_LIB, "rb").read()
+    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert i >= 0
+    n = struct.unpack_from("<Q", data, i + 24)[0]
+    off = i + 32
+    for _ in range(n):
+        o, sz, tl = struct.unpack_from("<QQQ", data, off)
+        off += 24
+        triple = data[off:off + tl]
+        off += tl
+        if b"gfx950" in triple:
+            path = tmp_path / "gfx950.co"
+            path.write_bytes(data[i + o:i + o + sz])
+            return str(path)
+    raise AssertionError("no gfx950 code object in the bundle")
+
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM_BIN, "llvm-readelf")), reason="ROCm LLVM tools not installed")
+def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_path):
+    """The LDS-DMA pipelines (blend_p3, blend_planar, blend_persist, blend_wave) wait with HAND-COUNTED `s_waitcnt vmcnt(n)`: n is the
+    number of vector-memory instructions the kernel itself issued after the DMA it waits for.  Anything the compiler adds to that
+    queue behind our back breaks the count silently: register spills (scratch loads / stores are vector-memory operations), or an
+    epilogue whose stores were merged or split.  So: none of these kernels may use scratch, and blend_p3's epilogues must consist of
+    twelve 8-byte stores and its DMA issue sites of six LDS loads each (the compiler may clone a site, never change its size)."""
+    co = _gfx950_code_object(native, tmp_path)
+    notes = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    kernels = {}
+    name = None
+    for line in notes.splitlines():
+        line = line.strip()
+        if line.startswith(".name:"):
+            name = line.split(":", 1)[1].strip()
+            kernels[name] = {}
+        elif name and ":" in line and line.split(":")[0] in (".private_segment_fixed_size", ".vgpr_spill_count", ".sgpr_spill_count", ".vgpr_count"):
+            kernels[name][line.split(":")[0]] = int(line.split(":")[1])
+    pipelined = [k for k in kernels if any(s in k for s in ("blend_p3", "blend_planar", "blend_persist", "blend_wave"))]
+    assert len(pipelined) >= 10, sorted(kernels)
+    for k in pipelined:
+        assert kernels[k][".private_segment_fixed_size"] == 0 and kernels[k][".vgpr_spill_count"] == 0, (k, kernels[k])
+        assert kernels[k][".vgpr_count"] <= 256, (k, kernels[k])          # two waves per SIMD: two workgroups per CU
+    dis = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+    body = {}
+    cur = None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            body[cur] = []
+        elif cur:
+            body[cur].append(line)
+    for k in [k for k in body if "blend_p3ILb1ELi" in k and k.endswith("ELi0EEEvNS_10KernelArgsEiii")]:
+        text = "\n".join(body[k])
+        n_st, n_dma = len(re.findall(r"global_store_dwordx2", text)), len(re.findall(r"global_load_lds_dwordx4", text))
+        assert n_st >= 12 and n_st % 12 == 0 and len(re.findall(r"global_store_", text)) == n_st, (k, n_st)
+        assert n_dma >= 18 and n_dma % 6 == 0, (k, n_dma)
+        assert "scratch_" not in text and "buffer_store" not in text and "buffer_load" not in text, k

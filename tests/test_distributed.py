@@ -97,3 +97,65 @@ def test_two_rank_view_sharding_matches_single_rank(native, oracle_c, tmp_path):
         assert (part == full[v0:v1]).all()
         covered += v1 - v0
     assert covered == total
+
+
+def test_image_slices_and_all_focus_rows(native):
+    """All-gather distribution: the ranks' image slices tile the grid in equal shares; the all-focus row reach contains the
+    fixed-focus reach and what the per-pixel warp can sample at both ends of the focus range."""
+    for n, world in ((64, 1), (64, 8), (225, 8), (225, 2), (9, 4), (3, 8)):
+        per = -(-n // world)
+        covered = []
+        for r in range(world):
+            g0, g1 = native.image_slice(n, world, r)
+            assert 0 <= g0 <= g1 <= n and g1 - g0 <= per
+            covered += list(range(g0, g1))
+        assert covered == list(range(n))
+    cols = rows = 8
+    W, H = 160, 120
+    hp = native.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.05, 0.12, 7.0, 1.783, 4)
+    for world in (2, 3, 8):
+        for rank in range(world):
+            band = native.row_band(H, world, rank)
+            lo, hi = native.input_rows_all_focus(band, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, H)
+            flo, fhi = native.input_rows(band, hp.focused_offsets, H)
+            assert 0 <= lo <= flo and fhi <= hi <= H
+            for g in range(cols * rows):
+                for f in (hp.focus, hp.focus + hp.range):
+                    for y in (band[0], band[1] - 1):
+                        sy = int(np.clip(int(np.float32(f) * np.float32(hp.offsets[g, 1]) + np.float32(y)), 0, H - 1))
+                        assert lo <= sy < hi
+
+
+def _allgather_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    import lfinterpolator_amd as L
+    from oracle import lfi_oracle_c as oc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, W, H = 9, 24, 10                      # 9 images over 2 ranks: shares of 5 and 4, the flat buffer is padded to 10 planes
+    plane = H * W * 4
+    per = -(-n // world)
+    flat = torch.zeros(per * world * plane, dtype=torch.uint8)
+    grid = flat[: n * plane].view(n, H, W, 4)
+    g0, g1 = L.image_slice(n, world, rank)
+    for g in range(g0, g1):                  # every rank produces ITS images only (bench.py: lfi_fill_synthetic_images)
+        grid[g].copy_(torch.from_numpy(oc.synthetic_plane(g, W, H, 0x1F1F)))
+    L.allgather_grid(flat, rank, world)
+    np.save(os.path.join(out_dir, f"grid_{rank}.npy"), grid.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_allgather_distribution(native, oracle_c, tmp_path):
+    """each rank contributes 1/G of the light field, one in-place all-gather (gloo here, RCCL on GPUs)
+    leaves the whole grid on every rank."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_allgather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = oracle_c.synthetic_lf(9, 24, 10, 0x1F1F)
+    for r in range(world):
+        assert (np.load(tmp_path / f"grid_{r}.npy") == want).all()

@@ -148,6 +148,38 @@ def test_pinned_host_buffers(gpu, oracle_c):
 
 
 
+def test_async_uploads_match_synchronous_ones(gpu, oracle_c):
+    """lfi_upload_image_async: pageable sources are staged through the page-locked ring (more images than slots, buffers reused
+    by the caller right after the call), page-locked sources are DMA'd in place; renders and a re-upload in the middle of a
+    sequence of launches are ordered after the copies without a host wait.  Bytes identical to synchronous uploads."""
+    cols, rows, W, H, V = 4, 4, 96, 40, 8
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.23, 0.0, 3.0, 1.783, V)
+    lf = oracle_c.synthetic_lf(16, W, H, SEED)
+    want = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.set_params(hp)
+    scratch = np.empty((H, W, 4), np.uint8)
+    for g in range(16):                       # one pageable buffer reused for every image: the call must have copy semantics
+        scratch[...] = lf[g]
+        ctx.upload_image_async(g, scratch)
+        scratch[...] = 0
+    ctx.render("STD")                          # no explicit wait: the launch is ordered after the copies
+    ctx.sync()
+    assert (ctx.download_views() == want).all()
+    pinned = ctx.pinned_empty((16, H, W, 4))
+    pinned[...] = lf[::-1]                     # a different grid: images reversed
+    for g in range(16):
+        ctx.upload_image_async(g, pinned[g])
+    ctx.render("TEN_WM")
+    ctx.upload_wait()
+    ctx.sync()
+    got = ctx.download_views()
+    want_rev = oracle_c.blend_ten(lf[::-1].copy(), hp.focused_offsets, hp.offsets, hp.weights)
+    assert np.abs(got.astype(int) - want_rev.astype(int)).max() <= 1
+    ctx.close()
+
+
 def test_input_changes_reach_the_renders(gpu, oracle_c):
     """TEN_WM renders read a derived (planar) copy of the inputs: every way of changing the inputs must reach them.
     Uploads through the ABI invalidate the copy; an attached buffer is read directly until lfi_grid_modified has been called,
