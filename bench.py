@@ -50,7 +50,6 @@ CONFIGS = {
     4: dict(cols=8, rows=8, W=3840, H=2160, views=256, traj="0.0,0.0,1.0,1.0", focus=0.23, rng=0.0, aspect=1.783, effect=3.0),
     5: dict(cols=15, rows=15, W=3840, H=2160, views=64, traj="0.071,0.071,0.93,0.93", focus=0.22, rng=0.17, aspect=1.783, effect=7.0),
 }
-TEN_PLANAR_VARIANTS = ("auto", "planar_m2_nt", "planar_m2", "planar_ring2_nt")
 
 
 def cpu_baseline(cfg, hp, threads: int) -> dict:

@@ -186,6 +186,16 @@ int lfi_focus_map(lfi_ctx *ctx);
 /* One launch of Tensors::process / Standard::process (src/interpolator.cu:274-288) for views [v0, v1).
  * all_focus != 0 selects the <true> instantiations (per-pixel focus from the focus map). */
 int lfi_render(lfi_ctx *ctx, int method, int all_focus, int v0, int v1);
+/* Trajectory streaming: renders a camera path of total_views views — weights_fp16 is [total_views][N], built
+ * for the WHOLE path by the host code (one trajectory centre, so the offsets set by lfi_set_params stay valid) — in blocks of V
+ * views (V = lfi_params.views) against the resident inputs, with no host synchronisation between blocks: block b+1's weight
+ * arrays are prepared on the host and copied while block b renders (page-locked double-buffered staging, stream-ordered device
+ * copy), and, when host_out != NULL, block b's views are copied to host_out + (b·V + v)·pitch_bytes·H on a second stream from a
+ * second set of views while block b+1 renders.  host_out should be page-locked (lfi_alloc_pinned) and needs the RGBA view
+ * layout; NULL renders only (the views of the last block remain on the device).  Returns after everything has completed.
+ * Afterwards the context's weights are those of the last block.  The reference renders exactly 64 views per run
+ * (src/kernels.cu:11-14); this is its loop over successive 64-view segments of a longer path. */
+int lfi_render_stream(lfi_ctx *ctx, int method, int all_focus, const uint16_t *weights_fp16, int total_views, uint8_t *host_out, size_t pitch_bytes);
 /* Do now what the first such lfi_render would otherwise do before its launch: (re)build the derived, alpha-free planar copy of
  * the inputs if that launch would read it, and time it.  Optional; synchronous.  No counterpart in the
  * reference (its surfaces are read as uploaded). */
@@ -220,6 +230,16 @@ int lfi_download_map(lfi_ctx *ctx, int k, uint8_t *rgba, size_t pitch_bytes);
  * rgba: (tiles_y*H) rows of pitch_bytes ≥ tiles_x*W*4.  Synchronous. */
 int lfi_download_quilt(lfi_ctx *ctx, int tiles_x, int tiles_y, int v0, uint8_t *rgba, size_t pitch_bytes);
 int lfi_upload_map(lfi_ctx *ctx, int k, const uint8_t *rgba, size_t pitch_bytes); /* tests: inject a focus map */
+
+/* PSNR / SSIM of rendered view v against a reference image on the host, reduced on the device — replaces
+ * scripts/imageQualityMetrics.sh:1-12 (ffmpeg psnr / ssim on two PNGs).  Definitions (csrc/hip/quality.hpp): PSNR per colour
+ * channel from the mean squared error over all pixels, "all" from the mean of the three MSEs; SSIM per channel = mean over all 8×8
+ * windows at stride 4 of the standard index with C1 = (0.01·255)², C2 = (0.03·255)², "all" = mean of the channels.  Synchronous. */
+typedef struct lfi_quality {
+    double mse[3], psnr[3], psnr_all; /* identical images: mse 0, psnr +inf */
+    double ssim[3], ssim_all;
+} lfi_quality;
+int lfi_compare_view(lfi_ctx *ctx, int v, const uint8_t *reference_rgba, size_t pitch_bytes, lfi_quality *out);
 
 /* Page-locked host memory for uploads / downloads at full PCIe rate (hipHostMalloc); optional — any host pointer works. */
 int lfi_alloc_pinned(size_t bytes, void **out_ptr);

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
     "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
-    "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_fill_synthetic_scene", "lfi_upload_image_async", "lfi_upload_wait", "lfi_debug_mfma_f16_chain",
+    "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_fill_synthetic_scene", "lfi_upload_image_async", "lfi_upload_wait", "lfi_render_stream", "lfi_compare_view", "lfi_debug_mfma_f16_chain",
 ]
 
 
@@ -50,6 +50,10 @@ LAYOUTS = {"rgba": LFI_LAYOUT_RGBA, "planar": LFI_LAYOUT_PLANAR_RGB}
 class ViewLayout(C.Structure):
     _fields_ = [("layout", C.c_int32), ("rows", C.c_int32), ("row_pitch_bytes", C.c_size_t), ("plane_stride_bytes", C.c_size_t),
                 ("view_stride_bytes", C.c_size_t)]
+
+
+class Quality(C.Structure):
+    _fields_ = [("mse", C.c_double * 3), ("psnr", C.c_double * 3), ("psnr_all", C.c_double), ("ssim", C.c_double * 3), ("ssim_all", C.c_double)]
 
 
 class MemoryInfo(C.Structure):
@@ -114,6 +118,8 @@ def load_hip_library() -> C.CDLL:
         "lfi_download_prequant": (i, [vp, i, i, i, vp]),
         "lfi_debug_mfma_f16": (i, [vp, vp, vp, vp]),
         "lfi_prepare": (i, [vp, i, i, i, i]),
+        "lfi_render_stream": (i, [vp, i, i, vp, i, vp, sz]),
+        "lfi_compare_view": (i, [vp, i, vp, sz, C.POINTER(Quality)]),
         "lfi_upload_image_async": (i, [vp, i, vp, sz]),
         "lfi_upload_wait": (i, [vp]),
         "lfi_fill_synthetic_scene": (i, [vp, C.c_uint32, C.c_float, C.c_float]),
@@ -304,6 +310,24 @@ class Context:
 
     def last_kernel_name(self) -> str:
         return self._lib.lfi_last_kernel_name(self._h).decode()
+
+    def render_stream(self, method, weights: np.ndarray, out: np.ndarray | None = None, all_focus: bool = False) -> None:
+        """weights: [total_views][N] fp16 bits of the whole path; out: None or a [total_views][H][W][4] u8 array (ideally from
+        pinned_empty) that receives every view."""
+        m = METHODS[method] if isinstance(method, str) else method
+        w = np.ascontiguousarray(weights, dtype=np.uint16)
+        assert w.ndim == 2 and w.shape[1] == self.n_images
+        if out is not None:
+            assert out.shape == (w.shape[0], self.height, self.width, 4) and out.dtype == np.uint8 and out.flags.c_contiguous
+        self._check(self._lib.lfi_render_stream(self._h, m, int(all_focus), _ptr(w), w.shape[0], _ptr(out) if out is not None else None,
+                                                self.width * 4))
+
+    def compare_view(self, v: int, reference: np.ndarray) -> Quality:
+        ref = np.ascontiguousarray(reference, dtype=np.uint8)
+        assert ref.shape == (self.height, self.width, 4)
+        q = Quality()
+        self._check(self._lib.lfi_compare_view(self._h, v, _ptr(ref), self.width * 4, C.byref(q)))
+        return q
 
     def benchmark(self, method, all_focus=False, v0=0, v1=None, warmup=3, runs=20) -> BenchStats:
         m = METHODS[method] if isinstance(method, str) else method

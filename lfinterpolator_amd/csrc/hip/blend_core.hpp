@@ -2,11 +2,11 @@
 // unit from LDS (TEN_WM: fp16 MFMA on subnormal pixel bytes; STD: exact fp32 MFMA) and the epilogue (quantise + stores).
 //
 // Layout the k-loops read: pixels [image][TPX] dwords (a lane's column pointer `col` is passed in), weight fragments
-// [k-octet][view] × 16 B (eight fp16, images 8o … 8o+7).  Operand maps: blend_ten.hpp; packed epilogue: blend_ten_lds.hpp.
+// [k-octet][view] × 16 B (eight fp16, images 8o … 8o+7).  Operand maps: blend_ten.hpp; packed epilogue: epilogue_packed.hpp.
 // Replaces the arithmetic of Kernels::Tensors::process / Kernels::Standard::process (reference src/kernels.cu:289-343, 398-461).
 #pragma once
 
-#include "blend_ten_lds.hpp"
+#include "epilogue_packed.hpp"
 
 namespace lfi {
 

@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
         for(int half = 0; half < 2; half++)
         {
 #define h(k) hq[24 * half + (k)]
-            // saturate at 255, then + 2.0 under round-toward-zero leaves floor(S) in the low mantissa byte (blend_ten_lds.hpp);
+            // saturate at 255, then + 2.0 under round-toward-zero leaves floor(S) in the low mantissa byte (epilogue_packed.hpp);
             // everything that depends on the fp16 rounding mode sits in ONE asm statement together with the two mode writes
             asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3\n\ts_nop 1\n\t" LFI_QA(0) LFI_QA(1) LFI_QA(2) LFI_QA(3) LFI_QA(4)
                              LFI_QA(5) LFI_QA(6) LFI_QA(7) LFI_QA(8) LFI_QA(9) LFI_QA(10) LFI_QA(11) LFI_QA(12) LFI_QA(13) LFI_QA(14)

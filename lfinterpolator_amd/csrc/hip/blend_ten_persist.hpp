@@ -24,7 +24,7 @@
 // stores, which is why the count of epilogue stores (a compile-time constant for full tiles, else we wait for everything)
 // appears in it.
 //
-// Contraction, operand maps, subnormal-pixel trick and packed epilogue: blend_ten.hpp / blend_ten_lds.hpp.
+// Contraction, operand maps, subnormal-pixel trick and packed epilogue: blend_ten.hpp / epilogue_packed.hpp.
 // Replaces Kernels::Tensors::process<allFocus> (reference src/kernels.cu:398-461).
 #pragma once
 

@@ -17,13 +17,13 @@
 #include "../../../include/lfi.h"
 #include "blend_std.hpp"
 #include "blend_ten.hpp"
-#include "blend_ten_lds.hpp"
 #include "blend_ten_persist.hpp"
 #include "blend_planar.hpp"
 #include "blend_p3.hpp"
 #include "blend_wave.hpp"
 #include "focus_factored.hpp"
 #include "lfi_device.hpp"
+#include "quality.hpp"
 
 using lfi::KernelArgs;
 
@@ -87,6 +87,16 @@ struct lfi_ctx
     bool have_params = false;
     int views_n = 0, k_pad = 0, v_pad = 0, n_focus_ids = 0;
     void *param_blob = nullptr; // one allocation holding all parameter arrays
+    size_t blob_off_w16 = 0, blob_weights_bytes = 0; // the four weight arrays inside the blob (what lfi_render_stream replaces per block)
+    // lfi_render_stream: page-locked staging for two blocks' weight arrays, a second set of views, events
+    uint8_t *stream_staging[2] = {nullptr, nullptr};
+    size_t stream_staging_bytes = 0;
+    uint8_t *views2 = nullptr;
+    size_t views2_bytes = 0;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_rendered[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
+    lfi::QualitySums *quality_sums = nullptr; // lfi_compare_view
+    uint8_t *quality_ref = nullptr;
+    size_t quality_ref_bytes = 0;
     lfi_int2 *d_focused = nullptr;
     lfi_float2 *d_offsets = nullptr;
     uint16_t *d_w16 = nullptr, *d_w16s = nullptr;
@@ -287,21 +297,6 @@ void launch_ten_direct(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
         hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false, false>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
 }
 
-template <int NT, int MT, int WPX, int WV, int KC, int WPE>
-void launch_ten_lds(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
-{
-    constexpr int TPX = WPX * NT * 32, VPP = WV * MT * 32;
-    const int tiles_x = (a.width + TPX - 1) / TPX;
-    const int n_tiles = tiles_x * a.height;
-    const int passes = (a.v1 - a.v0 + VPP - 1) / VPP;
-    const dim3 grid(n_tiles), block(WPX * WV * 64);
-    note_kernel(c, "blend_ten_lds");
-    if(all_focus)
-        hipLaunchKernelGGL((lfi::blend_ten_lds<NT, MT, WPX, WV, KC, WPE, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
-    else
-        hipLaunchKernelGGL((lfi::blend_ten_lds<NT, MT, WPX, WV, KC, WPE, false>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
-}
-
 template <bool STD, int MT, bool NT_STORE, int KC = 64, int WGS = 2>
 void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 {
@@ -406,29 +401,17 @@ void launch_std_vfma(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 // first entry = default ("auto")
 const Variant kTenVariants[] = {
     {"planar_m2_nt", launch_planar<true>, true, false, true, true}, // blend_persist where blend_planar does not apply
-    {"planar_m2", launch_planar<false>, true, false, true, true},
-    {"planar_ring2_nt", launch_planar<true, 0>, true, false, true, true},
     {"persist_m2_nt", launch_persist<false, 2, true>, true, false, true},
-    {"persist_m2", launch_persist<false, 2, false>, true, false, true},
     {"wave_m2_nt", launch_wave<false, 2, true>, true, false, true},
-    {"direct_p1m2", launch_ten_direct<1, 2>, false, true},
-    {"persist_m1", launch_persist<false, 1, true>, true, false, true},
-    {"lds_n1m2_w3", launch_ten_lds<1, 2, 4, 1, 64, 3>, true},
-    {"lds_n1m1_w4", launch_ten_lds<1, 1, 4, 1, 64, 4>, true},
-    {"lds_n2m1_w3", launch_ten_lds<2, 1, 2, 2, 64, 3>, true},
-    {"lds_n1m1x8_w2", launch_ten_lds<1, 1, 4, 2, 64, 2>, true},
-    {"direct_p2m2", launch_ten_direct<2, 2>, false, true},
-    {"direct_p2m1", launch_ten_direct<2, 1>, false, true},
-    {"direct_p4m1", launch_ten_direct<4, 1>, false, true},
-    {"direct_p1m1", launch_ten_direct<1, 1>, false, true},
+    {"direct_p1m2", launch_ten_direct<1, 2>, false, true}, // generic: any weights, pre-quantisation dump, per-batch rounding
 };
 const Variant kStdVariants[] = {
     {"filtered_m2_nt", launch_std_filtered, false, false, true, true}, // blend_wave / blend_persist where it does not apply
-    {"wave_m2_nt", launch_wave<true, 2, true>, false, false, true}, // blend_persist where blend_wave does not apply
+    {"wave_m2_nt", launch_wave<true, 2, true>, false, false, true},    // blend_persist where blend_wave does not apply
     {"persist_m2_nt", launch_persist<true, 2, true>, false, false, true},
-    {"persist_m1_nt", launch_persist<true, 1, true>, false, false, true},
-    {"mfma_p1m2", launch_std_mfma<1, 2>, false, true}, {"mfma_p2m2", launch_std_mfma<2, 2>, false, true}, {"mfma_p2m1", launch_std_mfma<2, 1>, false, true},
-    {"mfma_p4m1", launch_std_mfma<4, 1>, false, true}, {"valu", launch_std_valu, false, true}, {"vfma", launch_std_vfma, false, true},
+    {"mfma_p1m2", launch_std_mfma<1, 2>, false, true}, // generic: pre-quantisation dump
+    {"valu", launch_std_valu, false, true},             // the reference-shaped one-pixel-per-thread kernel: exactness anchor
+    {"vfma", launch_std_vfma, false, true},             // the non-tensor wavefront kernel
 };
 const int kNumTenVariants = sizeof(kTenVariants) / sizeof(kTenVariants[0]);
 const int kNumStdVariants = sizeof(kStdVariants) / sizeof(kStdVariants[0]);
@@ -679,6 +662,43 @@ int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a
     return LFI_OK;
 }
 
+// The four device forms of a block of `rows` weight rows: fp16 as given, ×2^15 (exact; valid iff every weight is finite and in
+// [0, 2)), f32, and f32 transposed — written at base + 0 / off_w16s / off_w32 / off_w32t (the region must be zero-initialised:
+// padding rows and images stay zero).  *scalable / *sums_ok: the dispatch conditions lfi_set_params records.
+void fill_weight_arrays(const uint16_t *weights_fp16, int rows, int n, int k_pad, int v_pad, uint8_t *base, size_t off_w16s, size_t off_w32, size_t off_w32t,
+                        bool *scalable_out, bool *sums_ok_out)
+{
+    uint16_t *w16 = reinterpret_cast<uint16_t *>(base);
+    uint16_t *w16s = reinterpret_cast<uint16_t *>(base + off_w16s);
+    float *w32 = reinterpret_cast<float *>(base + off_w32);
+    float *w32t = reinterpret_cast<float *>(base + off_w32t);
+    bool scalable = true;
+    for(int v = 0; v < rows; v++)
+        for(int g = 0; g < n; g++)
+        {
+            const uint16_t h = weights_fp16[(size_t)v * n + g];
+            const float f = static_cast<float>(__builtin_bit_cast(_Float16, h)); // half → float is exact
+            w16[(size_t)v * k_pad + g] = h;
+            // × 2^15 is exact in fp16 for every finite weight in [0, 2) (subnormals become normal, 1.999 → 65472)
+            if(!(f >= 0.0f && f < 2.0f))
+                scalable = false;
+            else
+                w16s[(size_t)v * k_pad + g] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(f * 32768.0f));
+            w32[(size_t)v * k_pad + g] = f;
+            w32t[(size_t)g * v_pad + v] = f;
+        }
+    bool sums_ok = scalable;
+    for(int v = 0; v < rows && sums_ok; v++)
+    {
+        double sum = 0;
+        for(int g = 0; g < n; g++)
+            sum += w32[(size_t)v * k_pad + g];
+        sums_ok = sum <= 2.0;
+    }
+    *scalable_out = scalable;
+    *sums_ok_out = sums_ok;
+}
+
 void free_params(lfi_ctx *c)
 {
     if(c->param_blob)
@@ -702,6 +722,14 @@ void free_views(lfi_ctx *c)
         (void)hipFree(c->dl_plane);
     c->dl_plane = nullptr;
     c->dl_plane_bytes = 0;
+    if(c->views2)
+        (void)hipFree(c->views2);
+    c->views2 = nullptr;
+    c->views2_bytes = 0;
+    if(c->quality_ref)
+        (void)hipFree(c->quality_ref);
+    c->quality_ref = nullptr;
+    c->quality_ref_bytes = 0;
 }
 
 // device pointer and pitch of view v as an RGBA plane of out_rows rows: the view itself, or (planar layout) its expansion into the
@@ -1001,6 +1029,19 @@ int lfi_destroy(lfi_ctx *ctx)
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
+    for(int i = 0; i < 2; i++)
+    {
+        if(ctx->stream_staging[i])
+            (void)hipHostFree(ctx->stream_staging[i]);
+        if(ctx->ev_h2d[i])
+            (void)hipEventDestroy(ctx->ev_h2d[i]);
+        if(ctx->ev_rendered[i])
+            (void)hipEventDestroy(ctx->ev_rendered[i]);
+        if(ctx->ev_d2h[i])
+            (void)hipEventDestroy(ctx->ev_d2h[i]);
+    }
+    if(ctx->quality_sums)
+        (void)hipFree(ctx->quality_sums);
     free_upload_ring(ctx);
     for(int i = 0; i < lfi_ctx::kUploadSlots; i++)
         if(ctx->upload_done[i])
@@ -1415,33 +1456,9 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
         fo_max[1] = std::max(fo_max[1], p->focused_offsets[g].y);
     }
     std::memcpy(blob.data() + off_offsets, p->offsets, sizeof(lfi_float2) * n);
-    uint16_t *w16 = reinterpret_cast<uint16_t *>(blob.data() + off_w16);
-    uint16_t *w16s = reinterpret_cast<uint16_t *>(blob.data() + off_w16s);
-    bool scalable = true;
-    float *w32 = reinterpret_cast<float *>(blob.data() + off_w32);
-    float *w32t = reinterpret_cast<float *>(blob.data() + off_w32t);
-    for(int v = 0; v < V; v++)
-        for(int g = 0; g < n; g++)
-        {
-            const uint16_t h = p->weights_fp16[(size_t)v * n + g];
-            const float f = static_cast<float>(__builtin_bit_cast(_Float16, h)); // half → float is exact
-            w16[(size_t)v * k_pad + g] = h;
-            // × 2^15 is exact in fp16 for every finite weight in [0, 2) (subnormals become normal, 1.999 → 65472)
-            if(!(f >= 0.0f && f < 2.0f))
-                scalable = false;
-            else
-                w16s[(size_t)v * k_pad + g] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(f * 32768.0f));
-            w32[(size_t)v * k_pad + g] = f;
-            w32t[(size_t)g * v_pad + v] = f;
-        }
-    bool sums_ok = scalable;
-    for(int v = 0; v < V && sums_ok; v++)
-    {
-        double sum = 0;
-        for(int g = 0; g < n; g++)
-            sum += w32[(size_t)v * k_pad + g];
-        sums_ok = sum <= 2.0;
-    }
+    bool scalable = true, sums_ok = true;
+    fill_weight_arrays(p->weights_fp16, V, n, k_pad, v_pad, blob.data() + off_w16, off_w16s - off_w16, off_w32 - off_w16, off_w32t - off_w16, &scalable,
+                       &sums_ok);
     if(p->n_focus_ids)
         std::memcpy(blob.data() + off_ids, p->focus_map_ids, sizeof(int32_t) * p->n_focus_ids);
 
@@ -1458,6 +1475,8 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     ctx->d_w32 = reinterpret_cast<float *>(base + off_w32);
     ctx->d_w32t = reinterpret_cast<float *>(base + off_w32t);
     ctx->d_ids = reinterpret_cast<int32_t *>(base + off_ids);
+    ctx->blob_off_w16 = off_w16;
+    ctx->blob_weights_bytes = off_ids - off_w16;
     ctx->k_pad = k_pad;
     ctx->v_pad = v_pad;
     ctx->views_n = V;
@@ -1618,10 +1637,8 @@ int lfi_focus_map(lfi_ctx *ctx)
         ;
     else if(ctx->focus_variant <= 1 && lds_fits) // "lds"
         hipLaunchKernelGGL(lfi::focus_estimate_lds, dim3((ctx->width + 127) / 128, ctx->height), dim3(64), 0, ctx->stream, a);
-    else if(ctx->focus_variant == 4) // "plain": one pixel per lane, float min/max exactly as the reference writes it
+    else if(ctx->focus_variant == 3) // "plain": one pixel per lane, float min/max exactly as the reference writes it
         hipLaunchKernelGGL(lfi::focus_estimate, pixel_grid(ctx), dim3(256), 0, ctx->stream, a);
-    else if(ctx->focus_variant == 3) // "packed_p4"
-        hipLaunchKernelGGL((lfi::focus_estimate_packed<4, 2>), dim3((ctx->width + 255) / 256, ctx->height), dim3(64), 0, ctx->stream, a);
     else // "packed_p2" (also the fallback of "lds" for very large radii)
         hipLaunchKernelGGL((lfi::focus_estimate_packed<2, 4>), dim3((ctx->width + 127) / 128, ctx->height), dim3(64), 0, ctx->stream, a);
     LFI_HIP(ctx, hipGetLastError());
@@ -1679,6 +1696,158 @@ int lfi_memory_info(lfi_ctx *ctx, lfi_memory *out)
 const char *lfi_last_kernel_name(const lfi_ctx *ctx)
 {
     return ctx ? ctx->last_kernel : "";
+}
+
+int lfi_render_stream(lfi_ctx *ctx, int method, int all_focus, const uint16_t *weights_fp16, int total_views, uint8_t *host_out, size_t pitch_bytes)
+{
+    if(int rc = check_render_args(ctx, method, 0, 1))
+        return rc;
+    if(!weights_fp16 || total_views < 1)
+        return fail(ctx, LFI_EINVAL, "lfi_render_stream: weights are NULL or total_views < 1");
+    if(host_out && (ctx->out_layout != LFI_LAYOUT_RGBA || pitch_bytes < (size_t)ctx->width * 4))
+        return fail(ctx, LFI_EINVAL, "lfi_render_stream: downloads need the RGBA view layout and a pitch of at least width*4 bytes");
+    if(int rc = bind(ctx))
+        return rc;
+    const int V = ctx->views_n, n = ctx->n, k_pad = ctx->k_pad, v_pad = ctx->v_pad;
+    const size_t wbytes = ctx->blob_weights_bytes;
+    const size_t off_w16s = (sizeof(uint16_t) * (size_t)v_pad * k_pad + 15) / 16 * 16; // the layout lfi_set_params laid out
+    const size_t off_w32 = (off_w16s + sizeof(uint16_t) * (size_t)v_pad * k_pad + 15) / 16 * 16;
+    const size_t off_w32t = off_w32 + sizeof(float) * (size_t)v_pad * k_pad;
+    if(ctx->stream_staging_bytes != wbytes)
+    {
+        for(int i = 0; i < 2; i++)
+        {
+            if(ctx->stream_staging[i])
+                (void)hipHostFree(ctx->stream_staging[i]);
+            ctx->stream_staging[i] = nullptr;
+        }
+        ctx->stream_staging_bytes = 0;
+        for(int i = 0; i < 2; i++)
+            LFI_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->stream_staging[i]), wbytes, hipHostMallocDefault));
+        ctx->stream_staging_bytes = wbytes;
+    }
+    for(int i = 0; i < 2; i++)
+        if(!ctx->ev_h2d[i])
+        {
+            LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_h2d[i], hipEventDisableTiming));
+            LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_rendered[i], hipEventDisableTiming));
+            LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_d2h[i], hipEventDisableTiming));
+        }
+    if(host_out)
+    {
+        if(!ctx->copy_stream)
+        {
+            LFI_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_uploads, hipEventDisableTiming));
+            for(int i = 0; i < lfi_ctx::kUploadSlots; i++)
+                LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->upload_done[i], hipEventDisableTiming));
+        }
+        const size_t need = out_plane_bytes(ctx) * V;
+        if(ctx->views2_bytes != need)
+        {
+            if(ctx->views2)
+                (void)hipFree(ctx->views2);
+            ctx->views2 = nullptr;
+            ctx->views2_bytes = 0;
+            LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->views2), need));
+            ctx->views2_bytes = need;
+        }
+    }
+    if(int rc = join_uploads(ctx))
+        return rc;
+    const int n_blocks = (total_views + V - 1) / V;
+    uint8_t *dev_weights = static_cast<uint8_t *>(ctx->param_blob) + ctx->blob_off_w16;
+    uint8_t *const vbuf[2] = {ctx->views, host_out ? ctx->views2 : ctx->views};
+    uint8_t *const views_saved = ctx->views;
+    int status = LFI_OK;
+    for(int b = 0; b < n_blocks && status == LFI_OK; b++)
+    {
+        const int slot = b & 1;
+        const int nv = std::min(V, total_views - b * V);
+        // the staging slot is free once the copy of block b − 2 out of it has been executed
+        if(b >= 2)
+            LFI_HIP(ctx, hipEventSynchronize(ctx->ev_h2d[slot]));
+        std::memset(ctx->stream_staging[slot], 0, wbytes);
+        bool scalable = true, sums_ok = true;
+        fill_weight_arrays(weights_fp16 + (size_t)b * V * n, nv, n, k_pad, v_pad, ctx->stream_staging[slot], off_w16s, off_w32, off_w32t, &scalable, &sums_ok);
+        ctx->weights_scalable = scalable; // the dispatch of THIS block's launch (read at enqueue time)
+        ctx->weights_sum_ok = sums_ok;
+        // stream order protects the device arrays: the previous block's kernel is ahead of this copy on the same stream
+        LFI_HIP(ctx, hipMemcpyAsync(dev_weights, ctx->stream_staging[slot], wbytes, hipMemcpyHostToDevice, ctx->stream));
+        LFI_HIP(ctx, hipEventRecord(ctx->ev_h2d[slot], ctx->stream));
+        if(host_out && b >= 2)
+            LFI_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_d2h[slot], 0)); // block b − 2 has left this set of views
+        ctx->views = vbuf[slot];
+        const KernelArgs a = make_args(ctx, 0, nv, method);
+        status = launch_blend(ctx, method, all_focus, a);
+        ctx->views = views_saved;
+        if(status != LFI_OK || !host_out)
+            continue;
+        LFI_HIP(ctx, hipEventRecord(ctx->ev_rendered[slot], ctx->stream));
+        LFI_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_rendered[slot], 0));
+        const size_t view_bytes = pitch_bytes * ctx->height;
+        for(int v = 0; v < nv; v++)
+            LFI_HIP(ctx, hipMemcpy2DAsync(host_out + ((size_t)b * V + v) * view_bytes + (size_t)ctx->out_y0 * pitch_bytes, pitch_bytes,
+                                          vbuf[slot] + out_plane_bytes(ctx) * v, (size_t)ctx->width * 4, (size_t)ctx->width * 4, ctx->out_rows,
+                                          hipMemcpyDeviceToHost, ctx->copy_stream));
+        LFI_HIP(ctx, hipEventRecord(ctx->ev_d2h[slot], ctx->copy_stream));
+    }
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if(host_out)
+        LFI_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    return status;
+}
+
+int lfi_compare_view(lfi_ctx *ctx, int v, const uint8_t *reference_rgba, size_t pitch_bytes, lfi_quality *out)
+{
+    if(!ctx || !out)
+        return LFI_EINVAL;
+    if(!ctx->views || !ctx->have_params)
+        return fail(ctx, LFI_EINVAL, "nothing rendered yet");
+    if(v < 0 || v >= ctx->views_n || !reference_rgba || pitch_bytes < (size_t)ctx->width * 4)
+        return fail(ctx, LFI_EINVAL, "bad view index, pointer or pitch");
+    if(ctx->windowed)
+        return fail(ctx, LFI_EINVAL, "lfi_compare_view needs the whole view (no row window)");
+    if(int rc = bind(ctx))
+        return rc;
+    const size_t need = plane_bytes(ctx);
+    if(ctx->quality_ref_bytes != need)
+    {
+        if(ctx->quality_ref)
+            (void)hipFree(ctx->quality_ref);
+        ctx->quality_ref = nullptr;
+        ctx->quality_ref_bytes = 0;
+        LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->quality_ref), need));
+        ctx->quality_ref_bytes = need;
+    }
+    if(!ctx->quality_sums)
+        LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->quality_sums), sizeof(lfi::QualitySums)));
+    LFI_HIP(ctx, hipMemcpy2DAsync(ctx->quality_ref, (size_t)ctx->width * 4, reference_rgba, pitch_bytes, (size_t)ctx->width * 4, ctx->height,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    LFI_HIP(ctx, hipMemsetAsync(ctx->quality_sums, 0, sizeof(lfi::QualitySums), ctx->stream));
+    const uint8_t *view = nullptr;
+    if(int rc = rgba_plane_of_view(ctx, v, &view))
+        return rc;
+    const int bw = (ctx->width + 3) / 4, bh = (ctx->height + 3) / 4; // 4×4 blocks
+    hipLaunchKernelGGL(lfi::quality_reduce, dim3((bw + 15) / 16, (bh + 15) / 16), dim3(256), 0, ctx->stream, reinterpret_cast<const uint32_t *>(view),
+                       reinterpret_cast<const uint32_t *>(ctx->quality_ref), ctx->width, ctx->height, ctx->quality_sums);
+    LFI_HIP(ctx, hipGetLastError());
+    lfi::QualitySums sums{};
+    LFI_HIP(ctx, hipMemcpyAsync(&sums, ctx->quality_sums, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream));
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double px = (double)ctx->width * ctx->height;
+    double mse_all = 0, ssim_all = 0;
+    for(int c = 0; c < 3; c++)
+    {
+        out->mse[c] = (double)sums.sq_err[c] / px;
+        out->psnr[c] = out->mse[c] > 0 ? 10.0 * std::log10(255.0 * 255.0 / out->mse[c]) : INFINITY;
+        out->ssim[c] = sums.windows ? sums.ssim[c] / (double)sums.windows : 1.0;
+        mse_all += out->mse[c] / 3.0;
+        ssim_all += out->ssim[c] / 3.0;
+    }
+    out->psnr_all = mse_all > 0 ? 10.0 * std::log10(255.0 * 255.0 / mse_all) : INFINITY;
+    out->ssim_all = ssim_all;
+    return LFI_OK;
 }
 
 int lfi_sync(lfi_ctx *ctx)
@@ -1879,7 +2048,7 @@ const char *lfi_list_variants(int method)
     if(method == LFI_METHOD_STD)
         return std_.c_str();
     if(method == LFI_KERNEL_FOCUS_ESTIMATE)
-        return "factored,lds,packed_p2,packed_p4,plain";
+        return "factored,lds,packed_p2,plain";
     return "";
 }
 
@@ -1918,13 +2087,13 @@ int lfi_set_variant(lfi_ctx *ctx, int method, const char *name)
     }
     else if(method == LFI_KERNEL_FOCUS_ESTIMATE)
     {
-        static const char *const names[] = {"factored", "lds", "packed_p2", "packed_p4", "plain"};
+        static const char *const names[] = {"factored", "lds", "packed_p2", "plain"};
         if(is_auto)
         {
             ctx->focus_variant = 0;
             return LFI_OK;
         }
-        for(int i = 0; i < 5; i++)
+        for(int i = 0; i < 4; i++)
             if(std::strcmp(name, names[i]) == 0)
             {
                 ctx->focus_variant = i;

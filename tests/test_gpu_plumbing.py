@@ -266,3 +266,85 @@ def test_stream_switch_orders_derived_state(gpu):
     ctx.set_stream(None)
     assert (ctx.download_views() == want).all()
     ctx.close()
+
+
+def test_render_stream_matches_block_by_block_renders(gpu, oracle_c):
+    """lfi_render_stream: a 37-view camera path rendered in blocks of 8 views with no host synchronisation in between (weights of
+    block b+1 staged and copied while block b renders, views of block b downloaded from a second buffer while block b+1
+    renders) gives, view for view, what separate set_params + render + download calls give — the last, partial block included."""
+    cols, rows, W, H, V, total = 4, 4, 200, 30, 8, 37
+    hp_all = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.2, 0.0, 3.0, 1.5, total)
+    lf = oracle_c.synthetic_lf(16, W, H, SEED)
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.upload_grid(lf)
+    for method in ("TEN_WM", "STD"):
+        want = np.zeros((total, H, W, 4), np.uint8)
+        for b in range(0, total, V):
+            hp = hp_all.rows(b, min(b + V, total))
+            ctx.set_params(hp)
+            ctx.render(method)
+            ctx.sync()
+            want[b:b + hp.weights.shape[0]] = ctx.download_views()
+        ctx.set_params(hp_all.rows(0, V))                    # the block size of the stream = the views of the parameters
+        out = ctx.pinned_empty((total, H, W, 4))
+        out[...] = 0
+        ctx.render_stream(method, hp_all.weights, out)
+        assert (out == want).all(), method
+        if method == "STD":
+            assert (want == oracle_c.blend_std(lf, hp_all.focused_offsets, hp_all.offsets, hp_all.weights)).all()
+        ctx.render_stream(method, hp_all.weights, None)     # render only: the last block's views stay on the device
+        assert (ctx.download_views(0, total - (total // V) * V) == want[(total // V) * V:]).all()
+    ctx.close()
+
+
+def _ssim_psnr_numpy(a, b):
+    """The definitions of csrc/hip/quality.hpp restated: per channel MSE over all pixels; SSIM = mean over 8×8 windows at stride 4."""
+    a = a[..., :3].astype(np.float64)
+    b = b[..., :3].astype(np.float64)
+    mse = ((a - b) ** 2).mean(axis=(0, 1))
+    H, W = a.shape[:2]
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    ssim = np.zeros(3)
+    count = 0
+    for y in range(0, H - 7, 4):
+        for x in range(0, W - 7, 4):
+            wa, wb = a[y:y + 8, x:x + 8].reshape(64, 3), b[y:y + 8, x:x + 8].reshape(64, 3)
+            mu1, mu2 = wa.mean(0), wb.mean(0)
+            var1, var2 = (wa * wa).mean(0) - mu1 * mu1, (wb * wb).mean(0) - mu2 * mu2
+            cov = (wa * wb).mean(0) - mu1 * mu2
+            ssim += ((2 * mu1 * mu2 + C1) * (2 * cov + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (var1 + var2 + C2))
+            count += 1
+    return mse, ssim / max(count, 1)
+
+
+def test_compare_view_psnr_ssim(gpu, oracle_c):
+    """lfi_compare_view (replaces scripts/imageQualityMetrics.sh): PSNR / SSIM of a rendered view against a host image, reduced on
+    the device, against the same definitions in numpy — STD vs TEN_WM renders of one view, an unrelated image, and the view itself."""
+    cols, rows, W, H, V = 4, 4, 150, 61, 4
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.2, 0.0, 3.0, 1.5, V)
+    lf = oracle_c.synthetic_lf(16, W, H, SEED)
+    lf[..., :3] = (lf[..., :3].astype(np.int32) // 3 + np.arange(W)[None, None, :, None] // 2).clip(0, 255).astype(np.uint8)  # some structure
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.upload_grid(lf)
+    ctx.set_params(hp)
+    ctx.render("STD")
+    ctx.sync()
+    std = ctx.download_views()
+    for layout in ("rgba", "planar"):
+        ctx.set_output_layout(layout)
+        ctx.render("TEN_WM")
+        ctx.sync()
+        ten = ctx.download_view(1)
+        for ref in (std[1], lf[3], ten):
+            q = ctx.compare_view(1, ref)
+            mse, ssim = _ssim_psnr_numpy(ten, ref)
+            assert np.allclose(list(q.mse), mse, rtol=1e-12, atol=0)
+            assert np.allclose(list(q.ssim), ssim, rtol=1e-9)
+            assert abs(q.ssim_all - ssim.mean()) < 1e-9
+            if mse.max() == 0:
+                assert q.psnr_all == float("inf") and abs(q.ssim_all - 1.0) < 1e-12
+            else:
+                assert abs(q.psnr_all - 10 * np.log10(255.0 ** 2 / mse.mean())) < 1e-9
+    ctx.close()

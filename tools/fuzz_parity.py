@@ -8,7 +8,7 @@ from oracle import lfi_oracle_c as oc
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-TEN = ["auto", "planar_ring2_nt", "persist_m2_nt", "wave_m2_nt"]
+TEN = ["auto", "persist_m2_nt", "wave_m2_nt"]
 STD = ["auto", "persist_m2_nt"]
 bad = 0
 for i in range(n_cases):
