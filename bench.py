@@ -170,7 +170,7 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
     # the focus sweep on a STRUCTURED light field: a texture seen at a piecewise-constant focus inside
     # [focus, focus + range], so that the estimated map is piecewise constant as on real scenes — on hash noise the map is noise and
     # the all-focus gathers touch one cache line per pixel (measured: 17 ms instead of ≈2 ms), which no real input does
-    ctx.fill_synthetic_scene(SEED, c5["focus"] + 0.1 * c5["rng"], c5["focus"] + 0.9 * c5["rng"])
+    ctx.fill_synthetic_scene(SEED)
     map_in = 4.0 * c5["W"] * c5["H"] * len(hp.focus_map_ids)          # the ≤32 sampled planes, read once by the estimate
     map_io = 4.0 * c5["W"] * c5["H"] * 3                                # map 0 written + read, map 1 written
     ms_map = timed(ctx, lambda: ctx.focus_map(), max(2, iters // 4), warm=1)
@@ -203,9 +203,10 @@ def main() -> int:
     ap.add_argument("--distribute", default="broadcast", choices=["broadcast", "allgather"],
                     help="how the grid reaches every GPU before the timed region: broadcast from rank 0 (north_star), or every rank "
                          "produces 1/G of the images and ONE all-gather assembles them (each xGMI link carries 1/G: SURVEY.md §5)")
-    ap.add_argument("--layout", default="rgba", choices=["rgba", "planar"],
-                    help="device layout of the rendered views: rgba = the reference's RGBA planes; planar = alpha-free byte planes "
-                         "(alpha is the constant 255 — src/kernels.cu:393 — and is re-created on download)")
+    ap.add_argument("--layout", default="planar", choices=["rgba", "planar"],
+                    help="device layout of the rendered views: planar (default) = alpha-free byte planes, the library's opt-in layout "
+                         "(the alpha the reference writes is the constant 255 — src/kernels.cu:393 — and is re-created on download, so "
+                         "what a caller downloads is byte-identical); rgba = the reference's RGBA planes (also timed, in `also`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the table of the other BASELINE configurations (N = 1 only)")
     ap.add_argument("--also-iters", type=int, default=12)

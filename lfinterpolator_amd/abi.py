@@ -122,7 +122,7 @@ def load_hip_library() -> C.CDLL:
         "lfi_compare_view": (i, [vp, i, vp, sz, C.POINTER(Quality)]),
         "lfi_upload_image_async": (i, [vp, i, vp, sz]),
         "lfi_upload_wait": (i, [vp]),
-        "lfi_fill_synthetic_scene": (i, [vp, C.c_uint32, C.c_float, C.c_float]),
+        "lfi_fill_synthetic_scene": (i, [vp, C.c_uint32]),
         "lfi_debug_mfma_f16_chain": (i, [vp, i, i, vp, vp, vp]),
         "lfi_set_output_layout": (i, [vp, i]),
         "lfi_view_layout": (i, [vp, C.POINTER(ViewLayout)]),
@@ -247,9 +247,9 @@ class Context:
         else:
             self._check(self._lib.lfi_fill_synthetic_images(self._h, seed, g0 or 0, self.n_images if g1 is None else g1))
 
-    def fill_synthetic_scene(self, seed: int, focus_lo: float, focus_hi: float) -> None:
+    def fill_synthetic_scene(self, seed: int) -> None:
         """Structured light field (texture at a piecewise-constant focus) for focus-map timing; call after set_params."""
-        self._check(self._lib.lfi_fill_synthetic_scene(self._h, seed, focus_lo, focus_hi))
+        self._check(self._lib.lfi_fill_synthetic_scene(self._h, seed))
 
     # -- parameters --------------------------------------------------------------------------------------------
     def set_params(self, hp, flags: int = 0) -> None:

@@ -520,12 +520,13 @@ __global__ void __launch_bounds__(256) fill_synthetic(uint8_t *__restrict__ grid
 }
 
 // A structured synthetic light field for focus-map measurements: a texture T of 4×4-pixel cells of random
-// colours seen at a piecewise-constant focus f*(block) (blocks of 256×256 pixels, four levels in [f_lo, f_hi]): image g shows
+// colours seen at a piecewise-constant focus f*(block) — blocks of 256×256 pixels, each at one of four of the estimate's own
+// candidates f_i = fma(range/31, i, focus), i ∈ {3, 11, 20, 28} (src/kernels.cu:245-249): image g shows
 // T(x − f*·offset_g.x, y − f*·offset_g.y), so sampling every image at p + f·offset_g (focusCoords, reference src/kernels.cu:78-82)
 // shows the same texel in all of them exactly when f = f* — the estimate then yields a piecewise-constant map, as real scenes do
 // and hash noise does not.  Same grid-stride shape as fill_synthetic.
 __global__ void __launch_bounds__(256) fill_scene(uint8_t *__restrict__ grid, const lfi_float2 *__restrict__ offsets, const int n_images, const int W,
-                                                 const int H, const int y0, const uint32_t seed, const float f_lo, const float f_hi)
+                                                 const int H, const int y0, const uint32_t seed, const float focus, const float range)
 {
     const size_t total = (size_t)n_images * W * H;
     for(size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
@@ -534,7 +535,7 @@ __global__ void __launch_bounds__(256) fill_scene(uint8_t *__restrict__ grid, co
         const int y = int((idx / W) % H) + y0;
         const int g = int(idx / ((size_t)W * H));
         const uint32_t level = mix32(seed ^ (uint32_t(x >> 8) * 73856093u) ^ (uint32_t(y >> 8) * 19349663u)) & 3u;
-        const float fs = f_lo + (f_hi - f_lo) * float(level) * (1.0f / 3.0f);
+        const float fs = __builtin_fmaf(__fdiv_rn(range, 31.0f), float(3u + 8u * level + (level >> 1)), focus); // candidates 3, 11, 20, 28
         const lfi_float2 off = offsets[g];
         const int u = int(floorf(float(x) - fs * off.x + 0.5f)), v = int(floorf(float(y) - fs * off.y + 0.5f));
         const uint32_t cell = mix32(mix32(seed + uint32_t(u >> 2) * 0x9e3779b9u) + uint32_t(v >> 2) * 0x85ebca6bu);

@@ -1383,7 +1383,7 @@ int lfi_fill_synthetic_images(lfi_ctx *ctx, uint32_t seed, int g0, int g1)
     return LFI_OK;
 }
 
-int lfi_fill_synthetic_scene(lfi_ctx *ctx, uint32_t seed, float focus_lo, float focus_hi)
+int lfi_fill_synthetic_scene(lfi_ctx *ctx, uint32_t seed)
 {
     if(!ctx)
         return LFI_EINVAL;
@@ -1393,7 +1393,7 @@ int lfi_fill_synthetic_scene(lfi_ctx *ctx, uint32_t seed, float focus_lo, float 
         return rc;
     ctx->grid_version++;
     hipLaunchKernelGGL(lfi::fill_scene, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, ctx->d_offsets, ctx->n, ctx->width, ctx->in_rows,
-                       ctx->in_y0, seed, focus_lo, focus_hi);
+                       ctx->in_y0, seed, ctx->focus, ctx->range);
     LFI_HIP(ctx, hipGetLastError());
     return LFI_OK;
 }
