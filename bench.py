@@ -316,9 +316,9 @@ def main() -> int:
         ctx.grid_modified()              # attached planes: announce that they are final
     ctx.set_params(hp)
     out_bpp = 4 if args.layout == "rgba" else 3
-    views = torch.empty((views_per_gpu * out_rows_n * WIDTH * out_bpp,), dtype=torch.uint8, device=dev)
     if args.layout != "rgba":
         ctx.set_output_layout(args.layout)
+    views = torch.empty((views_per_gpu * ctx.view_layout().view_stride_bytes,), dtype=torch.uint8, device=dev)
     ctx.attach_views(views.data_ptr(), views.numel())
     ctx.set_variant(args.method, args.variant)
     ctx.prepare(args.method)             # the derived planar input copy is built (and timed) here, not in the first launch

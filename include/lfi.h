@@ -149,8 +149,8 @@ int lfi_grid_modified(lfi_ctx *ctx);
 int lfi_fill_synthetic(lfi_ctx *ctx, uint32_t seed);
 /* the same for images [g0, g1) only — a rank of an all-gather distribution generates (or uploads) just its own slice */
 int lfi_fill_synthetic_images(lfi_ctx *ctx, uint32_t seed, int g0, int g1);
-/* a STRUCTURED synthetic light field for focus-map measurements: a texture of 4×4-pixel cells seen at a
- * piecewise-constant focus (256×256-pixel blocks, each at one of four of the estimate's candidates inside [focus, focus + range]
+/* a STRUCTURED synthetic light field for focus-map measurements: a texture of 8×8-pixel cells seen at a
+ * piecewise-constant focus (1024×1024-pixel blocks, each at one of four of the estimate's candidates inside [focus, focus + range]
  * of the current parameters) — image g shows T(p − f*·offsets[g]), so the estimate finds a piecewise-constant map as in real
  * scenes (hash noise gives a noise map, and all-focus renders from a noise map gather one cache line per pixel).  Needs
  * lfi_set_params (offsets, focus, range).  Measurement only. */

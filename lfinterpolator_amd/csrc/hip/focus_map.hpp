@@ -519,8 +519,8 @@ __global__ void __launch_bounds__(256) fill_synthetic(uint8_t *__restrict__ grid
     }
 }
 
-// A structured synthetic light field for focus-map measurements: a texture T of 4×4-pixel cells of random
-// colours seen at a piecewise-constant focus f*(block) — blocks of 256×256 pixels, each at one of four of the estimate's own
+// A structured synthetic light field for focus-map measurements: a texture T of 8×8-pixel cells of random
+// colours seen at a piecewise-constant focus f*(block) — blocks of 1024×1024 pixels, each at one of four of the estimate's own
 // candidates f_i = fma(range/31, i, focus), i ∈ {3, 11, 20, 28} (src/kernels.cu:245-249): image g shows
 // T(x − f*·offset_g.x, y − f*·offset_g.y), so sampling every image at p + f·offset_g (focusCoords, reference src/kernels.cu:78-82)
 // shows the same texel in all of them exactly when f = f* — the estimate then yields a piecewise-constant map, as real scenes do
@@ -534,11 +534,12 @@ __global__ void __launch_bounds__(256) fill_scene(uint8_t *__restrict__ grid, co
         const int x = int(idx % W);
         const int y = int((idx / W) % H) + y0;
         const int g = int(idx / ((size_t)W * H));
-        const uint32_t level = mix32(seed ^ (uint32_t(x >> 8) * 73856093u) ^ (uint32_t(y >> 8) * 19349663u)) & 3u;
+        const uint32_t level = mix32(seed ^ (uint32_t(x >> 10) * 73856093u) ^ (uint32_t(y >> 10) * 19349663u)) & 3u;
         const float fs = __builtin_fmaf(__fdiv_rn(range, 31.0f), float(3u + 8u * level + (level >> 1)), focus); // candidates 3, 11, 20, 28
         const lfi_float2 off = offsets[g];
-        const int u = int(floorf(float(x) - fs * off.x + 0.5f)), v = int(floorf(float(y) - fs * off.y + 0.5f));
-        const uint32_t cell = mix32(mix32(seed + uint32_t(u >> 2) * 0x9e3779b9u) + uint32_t(v >> 2) * 0x85ebca6bu);
+        // the integer shift the warp applies at f*: (int)fma(f, offset, coord) = coord + floor(f·offset) wherever the sum is ≥ 0
+        const int u = x - int(floorf(fs * off.x)), v = y - int(floorf(fs * off.y));
+        const uint32_t cell = mix32(mix32(seed + uint32_t(u >> 3) * 0x9e3779b9u) + uint32_t(v >> 3) * 0x85ebca6bu);
         reinterpret_cast<uint32_t *>(grid)[idx] = 0xff000000u | (cell & 0x00ffffffu);
     }
 }
