@@ -1,11 +1,18 @@
+"""Launch the focus-map estimate + filter a few times (for rocprofv3 runs).  usage: python tools/run_focus.py [variant] [cols W H] [scene]"""
 import sys
 sys.path.insert(0, ".")
 import lfinterpolator_amd as L
-cols = rows = 8; W, H = 1920, 1080
-ctx = L.Context(0); ctx.set_grid(cols, rows, W, H); ctx.fill_synthetic(0x1F1F)
-ctx.set_params(L.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.22, 0.17, 7.0, 1.783, 64))
-if len(sys.argv) > 1:
-    ctx.set_variant("FOCUS", sys.argv[1])
+variant = sys.argv[1] if len(sys.argv) > 1 else "auto"
+cols = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
+H = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
+ctx = L.Context(0); ctx.set_grid(cols, cols, W, H)
+ctx.set_params(L.build_params(cols, cols, W, H, "0.071,0.071,0.93,0.93", 0.22, 0.17, 7.0, 1.783, 64))
+if len(sys.argv) > 5 and sys.argv[5] == "scene":
+    ctx.fill_synthetic_scene(0x1F1F)
+else:
+    ctx.fill_synthetic(0x1F1F)
+ctx.set_variant("FOCUS", variant)
 for _ in range(5):
     ctx.focus_map(); ctx.sync()
 ctx.close()
