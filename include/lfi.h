@@ -118,11 +118,12 @@ int lfi_set_grid(lfi_ctx *ctx, int cols, int rows, int width, int height);
 int lfi_set_row_window(lfi_ctx *ctx, int out_y0, int out_y1, int in_y0, int in_y1);
 /* cudaMemcpy2DToArray of one image (src/interpolator.cu:91): copies; the caller keeps ownership.  Synchronous. */
 int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_bytes);
-/* The same copy, asynchronous: enqueued on the context's copy stream, so that the host can decode or read the
- * next image — and the GPU can render — while this one crosses PCIe.  A pageable source is first copied into a ring of
- * page-locked staging slots (copy semantics: the caller's buffer is free on return); a page-locked source (lfi_alloc_pinned) is
- * DMA'd in place and must stay valid until lfi_upload_wait / lfi_sync.  Everything that uses the planes afterwards (renders,
- * focus map, fills, downloads of results) is ordered after the pending copies by an event, without a host wait. */
+/* The same copy, asynchronous: enqueued on the context's copy stream — no synchronisation with the compute
+ * stream per image, the GPU keeps rendering while images cross PCIe.  A page-locked source (lfi_alloc_pinned) is DMA'd in place:
+ * the call returns at once and the buffer must stay valid until lfi_upload_wait / lfi_sync.  A pageable source is staged by the
+ * HIP runtime before the call returns (the buffer is free on return; the host thread is busy for the copy's duration).
+ * Everything that uses the planes afterwards (renders, focus map, fills) is ordered after the pending copies by an event,
+ * without a host wait. */
 int lfi_upload_image_async(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_bytes);
 /* host wait for the asynchronous uploads issued so far */
 int lfi_upload_wait(lfi_ctx *ctx);

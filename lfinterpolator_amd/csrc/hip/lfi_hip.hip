@@ -54,14 +54,8 @@ struct lfi_ctx
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_order = nullptr; // orders the work of the stream a caller switches away from before the stream it switches to
-    // asynchronous uploads (lfi_upload_image_async): a copy stream, a ring of page-locked staging slots for pageable sources
-    static constexpr int kUploadSlots = 4;
+    // asynchronous uploads (lfi_upload_image_async) and downloads of lfi_render_stream: a copy stream
     hipStream_t copy_stream = nullptr;
-    uint8_t *upload_slot[kUploadSlots] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t upload_done[kUploadSlots] = {nullptr, nullptr, nullptr, nullptr};
-    bool upload_slot_used[kUploadSlots] = {false, false, false, false};
-    size_t upload_slot_bytes = 0;
-    int upload_next = 0;
     bool uploads_pending = false; // copies enqueued on copy_stream that the compute stream has not been ordered after yet
     hipEvent_t ev_uploads = nullptr;
     // side stream of the factored focus-map estimate (its small passes overlap the large ones), created on first use
@@ -162,16 +156,13 @@ int join_uploads(lfi_ctx *c)
     return LFI_OK;
 }
 
-void free_upload_ring(lfi_ctx *c)
+int ensure_copy_stream(lfi_ctx *c)
 {
-    for(int i = 0; i < lfi_ctx::kUploadSlots; i++)
-    {
-        if(c->upload_slot[i])
-            (void)hipHostFree(c->upload_slot[i]);
-        c->upload_slot[i] = nullptr;
-        c->upload_slot_used[i] = false;
-    }
-    c->upload_slot_bytes = 0;
+    if(c->copy_stream)
+        return LFI_OK;
+    LFI_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    LFI_HIP(c, hipEventCreateWithFlags(&c->ev_uploads, hipEventDisableTiming));
+    return LFI_OK;
 }
 
 size_t plane_bytes(const lfi_ctx *c) // a whole-image plane (focus maps; inputs and outputs without a row window)
@@ -1042,10 +1033,6 @@ int lfi_destroy(lfi_ctx *ctx)
     }
     if(ctx->quality_sums)
         (void)hipFree(ctx->quality_sums);
-    free_upload_ring(ctx);
-    for(int i = 0; i < lfi_ctx::kUploadSlots; i++)
-        if(ctx->upload_done[i])
-            (void)hipEventDestroy(ctx->upload_done[i]);
     if(ctx->ev_uploads)
         (void)hipEventDestroy(ctx->ev_uploads);
     if(ctx->ev_fork)
@@ -1179,49 +1166,21 @@ int lfi_upload_image_async(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitc
         return fail(ctx, LFI_EINVAL, "bad image index, pointer or pitch");
     if(int rc = bind(ctx))
         return rc;
-    if(!ctx->copy_stream)
-    {
-        LFI_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-        LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_uploads, hipEventDisableTiming));
-        for(int i = 0; i < lfi_ctx::kUploadSlots; i++)
-            LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->upload_done[i], hipEventDisableTiming));
-    }
+    if(int rc = ensure_copy_stream(ctx))
+        return rc;
     if(!ctx->uploads_pending)
     {
         // first copy of a batch: renders already enqueued on the compute stream may still read the planes
         LFI_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
         LFI_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_order, 0));
     }
+    // rgba addresses row 0 of the whole image; the rows this context holds are copied.  A page-locked source is DMA'd in place
+    // (the call returns at once); a pageable one is staged by the HIP runtime through its own page-locked buffers before the call
+    // returns (≈45–50 GB/s of host time on this platform — a staging ring of our own with a host memcpy in front measured
+    // 20 GB/s, profiles/r02_upload_time.txt), so the caller's buffer is free on return either way.
     const size_t row_bytes = (size_t)ctx->width * 4;
-    const uint8_t *src = rgba + (size_t)ctx->in_y0 * pitch_bytes; // rgba addresses row 0 of the whole image; the held rows are copied
-    size_t src_pitch = pitch_bytes;
-    hipPointerAttribute_t attr{};
-    const bool page_locked = hipPointerGetAttributes(&attr, rgba) == hipSuccess && attr.type == hipMemoryTypeHost;
-    if(!page_locked)
-    {
-        (void)hipGetLastError(); // pageable memory is "invalid value" to the query
-        // pageable source: stage it through a page-locked slot (the call has copy semantics: the caller's buffer is free on return)
-        const size_t need = row_bytes * ctx->in_rows;
-        if(ctx->upload_slot_bytes != need)
-        {
-            LFI_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-            free_upload_ring(ctx);
-            for(int i = 0; i < lfi_ctx::kUploadSlots; i++)
-                LFI_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->upload_slot[i]), need, hipHostMallocDefault));
-            ctx->upload_slot_bytes = need;
-        }
-        const int slot = ctx->upload_next++ % lfi_ctx::kUploadSlots;
-        if(ctx->upload_slot_used[slot])
-            LFI_HIP(ctx, hipEventSynchronize(ctx->upload_done[slot])); // its previous copy has left the slot
-        for(int y = 0; y < ctx->in_rows; y++)
-            std::memcpy(ctx->upload_slot[slot] + (size_t)y * row_bytes, src + (size_t)y * pitch_bytes, row_bytes);
-        LFI_HIP(ctx, hipMemcpyAsync(ctx->grid + in_plane_bytes(ctx) * g, ctx->upload_slot[slot], need, hipMemcpyHostToDevice, ctx->copy_stream));
-        LFI_HIP(ctx, hipEventRecord(ctx->upload_done[slot], ctx->copy_stream));
-        ctx->upload_slot_used[slot] = true;
-    }
-    else
-        LFI_HIP(ctx, hipMemcpy2DAsync(ctx->grid + in_plane_bytes(ctx) * g, row_bytes, src, src_pitch, row_bytes, ctx->in_rows, hipMemcpyHostToDevice,
-                                      ctx->copy_stream));
+    LFI_HIP(ctx, hipMemcpy2DAsync(ctx->grid + in_plane_bytes(ctx) * g, row_bytes, rgba + (size_t)ctx->in_y0 * pitch_bytes, pitch_bytes, row_bytes,
+                                  ctx->in_rows, hipMemcpyHostToDevice, ctx->copy_stream));
     ctx->uploads_pending = true;
     ctx->grid_version++;
     return LFI_OK;
@@ -1735,13 +1694,8 @@ int lfi_render_stream(lfi_ctx *ctx, int method, int all_focus, const uint16_t *w
         }
     if(host_out)
     {
-        if(!ctx->copy_stream)
-        {
-            LFI_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-            LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_uploads, hipEventDisableTiming));
-            for(int i = 0; i < lfi_ctx::kUploadSlots; i++)
-                LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->upload_done[i], hipEventDisableTiming));
-        }
+        if(int rc = ensure_copy_stream(ctx))
+            return rc;
         const size_t need = out_plane_bytes(ctx) * V;
         if(ctx->views2_bytes != need)
         {
