@@ -333,15 +333,40 @@ __global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const Foc
     for(int c = 0; c < CPW; c++)
         acc[c].init();
     const int n_ids = a.n_focus_ids;
-    for(int k = 0; k < n_ids; k++)
+    // Software pipeline over the views (round 2: the loop used to load a view's four deltas through the scalar cache, wait, load
+    // its four sample vectors, wait, and only then reduce — both latencies exposed per view): the samples of view k + 1 are in
+    // flight while view k is reduced, and the deltas of view k + 2 are already on their way through the scalar cache.
+    auto load_deltas = [&](const int k, int64_t (&d)[CPW]) {
+#pragma unroll
+        for(int c = 0; c < CPW; c++)
+            d[c] = deltas[c * FOCUS_MAX_IDS + k];
+    };
+    auto load_samples = [&](const int64_t (&d)[CPW], u32x4 (&px)[CPW]) {
+#pragma unroll
+        for(int c = 0; c < CPW; c++)
+            px[c] = *reinterpret_cast<const u32x4_a4 *>(wave_base + d[c] + lane_off);
+    };
+    // No branches in the loop: past the last view the indices clamp to it — reducing a view twice changes no minimum or maximum —
+    // so the compiler's vmcnt / lgkmcnt counts are exact (with conditional loads it has to assume they were not issued and waits
+    // for everything).
+    int64_t dA[CPW], dB[CPW];
+    u32x4 pA[CPW], pB[CPW];
+    const int last = n_ids - 1;
+    load_deltas(0, dA);
+    load_samples(dA, pA);
+    load_deltas(min(1, last), dB);
+    for(int k = 0; k < n_ids; k += 2)
     {
-        u32x4 px[CPW];
+        load_samples(dB, pB);                 // view k + 1
+        load_deltas(min(k + 2, last), dA);
 #pragma unroll
         for(int c = 0; c < CPW; c++)
-            px[c] = *reinterpret_cast<const u32x4_a4 *>(wave_base + deltas[c * FOCUS_MAX_IDS + k] + lane_off);
+            acc[c].add(pA[c]);                // view k
+        load_samples(dA, pA);                 // view k + 2
+        load_deltas(min(k + 3, last), dB);
 #pragma unroll
         for(int c = 0; c < CPW; c++)
-            acc[c].add(px[c]);
+            acc[c].add(pB[c]);                // view k + 1
     }
 #pragma unroll
     for(int c = 0; c < CPW; c++)

@@ -149,9 +149,9 @@ def test_pinned_host_buffers(gpu, oracle_c):
 
 
 def test_async_uploads_match_synchronous_ones(gpu, oracle_c):
-    """lfi_upload_image_async: pageable sources are staged through the page-locked ring (more images than slots, buffers reused
-    by the caller right after the call), page-locked sources are DMA'd in place; renders and a re-upload in the middle of a
-    sequence of launches are ordered after the copies without a host wait.  Bytes identical to synchronous uploads."""
+    """lfi_upload_image_async: pageable sources have copy semantics (one buffer reused by the caller right after every call),
+    page-locked sources are DMA'd in place; renders and a re-upload in the middle of a sequence of launches are ordered after the
+    copies without a host wait.  Bytes identical to synchronous uploads."""
     cols, rows, W, H, V = 4, 4, 96, 40, 8
     hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.23, 0.0, 3.0, 1.783, V)
     lf = oracle_c.synthetic_lf(16, W, H, SEED)

@@ -38,6 +38,18 @@ for i in range(n_cases):
         part = ctx.download_views()
         if d > 1 or not (part == full).all():
             bad += 1; print("TEN MISMATCH", var, d, cols, rows, W, H, V, focus, traj, v0, v1)
+    # the planar view layout (blend_p3): byte-identical to the RGBA layout's default kernel, view ranges included
+    ctx.set_variant("TEN_WM", "auto"); ctx.set_variant("STD", "auto")
+    ctx.render("TEN_WM"); ctx.sync()
+    want_rgba = ctx.download_views()
+    ctx.set_output_layout("planar")
+    ctx.render("TEN_WM"); ctx.sync()
+    got = ctx.download_views()
+    ctx.render("TEN_WM", v0=v0, v1=v1); ctx.sync()
+    part = ctx.download_views()
+    ctx.render("STD"); ctx.sync()
+    if not (got == want_rgba).all() or not (part == got).all() or not (ctx.download_views() == want_std).all():
+        bad += 1; print("PLANAR LAYOUT MISMATCH", ctx.last_kernel_name(), cols, rows, W, H, V, focus, traj, v0, v1)
     ctx.close()
     if (i + 1) % 20 == 0:
         print(f"{i + 1} cases, {bad} mismatches", flush=True)
