@@ -104,11 +104,14 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
     __syncthreads(); // the offset table is complete
 
     // pixel bytes of one unit: piece p (1 KB) = channel p / 8, octet p % 8 of the chunk; wave w moves pieces w, w + 4, …, i.e.
-    // octets w and w + 4 of every channel.  Per octet a lane needs its image's integer offsets and (channel 0) plane.
+    // octets w and w + 4 of every channel.  Addressing: a wave-uniform 64-bit base per octet and channel (SGPR pair: the plane of
+    // the octet's first image) + a 32-bit per-lane byte offset (the lane's image inside the octet, its row and column) — no 64-bit
+    // vector arithmetic in the loop.  Per octet a lane keeps its image's integer offsets and its image's distance from the base.
     struct Pieces
     {
         int ox[2], oy[2];
-        size_t plane0[2];
+        uint32_t img_off[2]; // (this lane's image − the octet's first image) · 12 planes, in bytes (< 2^32: checked on the host)
+        int g_base[2];       // the octet's first image (wave-uniform), clamped to the last image
     };
     auto lookup = [&](const int chunk) {
         Pieces pc;
@@ -116,11 +119,13 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
         for(int o2 = 0; o2 < 2; o2++)
         {
             const int octet = wave + 4 * o2;
-            const int g = min(P3_KC * chunk + 8 * octet + (lane >> 3), a.n_images - 1); // padded images (zero weights) re-read the last one
-            const int2 o = off_table[g];
+            const int g_base = min(P3_KC * chunk + 8 * octet, a.n_images - 1);
+            const int dg = min(lane >> 3, a.n_images - 1 - g_base); // padded images (zero weights) re-read the last one
+            const int2 o = off_table[g_base + dg];
             pc.ox[o2] = o.x;
             pc.oy[o2] = o.y;
-            pc.plane0[o2] = (size_t)g * 12 * shift_stride;
+            pc.img_off[o2] = uint32_t(dg) * 12u * uint32_t(shift_stride);
+            pc.g_base[o2] = g_base;
         }
         return pc;
     };
@@ -144,16 +149,17 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
             const int k = start & 3;
             // (k·rows + sy)·pitch with full-rate 24-bit multiplies (rows, pitch < 2^24; the product < 2^32: checked on the host)
             const uint32_t row_off = __umul24(__umul24(uint32_t(k), uint32_t(a.in_rows)) + uint32_t(sy), uint32_t(a.planar_pitch));
-            const uint8_t *src = a.planar + pc.plane0[o2] + row_off + (start - k) + 16 * (lane & 7);
+            const uint32_t voff = pc.img_off[o2] + row_off + uint32_t(start - k) + 16u * uint32_t(lane & 7);
+            const uint8_t *sbase = a.planar + (size_t)__builtin_amdgcn_readfirstlane(pc.g_base[o2]) * 12 * shift_stride;
             if constexpr(ABL != 2)
             {
 #pragma unroll
                 for(int ch = 0; ch < 3; ch++)
-                    dma16(src + (size_t)ch * 4 * shift_stride, dst + uint32_t(ch * P3_CH_B + p3_octet_off(octet)));
+                    dma16_s(sbase + (size_t)ch * 4 * shift_stride, voff, dst + uint32_t(ch * P3_CH_B + p3_octet_off(octet)));
                 count += 3;
             }
             else
-                asm volatile("" ::"v"(src), "s"(dst));
+                asm volatile("" ::"v"(voff), "s"(sbase), "s"(dst));
         }
         return count;
     };

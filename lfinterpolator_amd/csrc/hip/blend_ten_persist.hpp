@@ -49,6 +49,11 @@ __device__ __forceinline__ void dma4_s(const void *sbase, uint32_t voff, uint32_
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
 }
 
+__device__ __forceinline__ void dma16_s(const void *sbase, uint32_t voff, uint32_t lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+}
+
 template <int MT, int KC_>
 struct PersistCfg
 {

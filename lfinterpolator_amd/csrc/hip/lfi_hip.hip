@@ -456,8 +456,9 @@ bool ensure_planar(lfi_ctx *c)
         return true;
     const int padx = std::max(need, c->planar_padx);
     const int pitch = (c->width + 2 * padx + 15) / 16 * 16;
-    // blend_p3 addresses a row as (shift·rows + row)·pitch with 24-bit multiplies and a 32-bit product
-    if(c->in_rows >= (1 << 22) || pitch >= (1 << 24) || (uint64_t)4 * c->in_rows * pitch >= (1ull << 32))
+    // blend_p3 addresses a row as (shift·rows + row)·pitch with 24-bit multiplies, and a lane's byte inside its octet of images (8
+    // images × 12 planes) with 32 bits
+    if(c->in_rows >= (1 << 22) || pitch >= (1 << 24) || (uint64_t)100 * c->in_rows * pitch >= (1ull << 32))
         return false;
     const size_t bytes = (size_t)c->n * 12 * c->in_rows * pitch; // the rows this context holds (a row window: band + halo)
     if(bytes != c->planar_bytes)
