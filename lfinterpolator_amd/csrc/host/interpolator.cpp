@@ -133,6 +133,11 @@ void Interpolator::interpolate(std::string outputPath, std::string trajectory, f
     if(gpuCount < 1 || gpuCount > viewCount)
         throw std::runtime_error("The number of GPUs has to be between 1 and the number of views!");
     shardOverGpus(params);
+    // The views never leave the library except through lfi_download_view / _quilt, which re-create the constant alpha: fixed-focus
+    // TEN_WM renders therefore use the alpha-free byte-plane layout (a quarter fewer bytes written per launch, csrc/hip/blend_p3.hpp);
+    // the other renders keep the reference's RGBA planes (they would pay a conversion pass).  Output files are identical.
+    for(lfi_ctx *c : contexts)
+        check(lfi_set_output_layout(c, (methodID == LFI_METHOD_TEN_WM && !(inRange > 0)) ? LFI_LAYOUT_PLANAR_RGB : LFI_LAYOUT_RGBA), c);
 
     const int allFocus = inRange > 0;
     if(allFocus)

@@ -348,3 +348,36 @@ def test_compare_view_psnr_ssim(gpu, oracle_c):
             else:
                 assert abs(q.psnr_all - 10 * np.log10(255.0 ** 2 / mse.mean())) < 1e-9
     ctx.close()
+
+
+def test_prepare_memory_info_and_partial_fills(gpu, oracle_c):
+    """lfi_prepare builds (and times) the derived planar copy ahead of the first render; lfi_memory_info reports what the context
+    holds; lfi_fill_synthetic_images fills a slice of the grid (the all-gather distribution's per-rank share); the structured scene
+    fill runs and changes the inputs."""
+    cols, rows, W, H, V = 4, 4, 256, 64, 8
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.2, 0.1, 3.0, 1.5, V)
+    ctx.set_params(hp)
+    ctx.fill_synthetic(SEED, 0, 5)
+    ctx.fill_synthetic(SEED, 5, 16)
+    mi = ctx.memory_info()
+    assert mi.grid_bytes == 16 * W * H * 4 and mi.derived_bytes == 0 and mi.views_bytes == V * W * H * 4
+    ctx.prepare("TEN_WM")
+    mi = ctx.memory_info()
+    assert mi.derived_bytes >= 12 * 16 * W * H and mi.derived_build_ms > 0
+    ctx.render("STD")
+    ctx.sync()
+    lf = oracle_c.synthetic_lf(16, W, H, SEED)
+    assert (ctx.download_views() == oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)).all()
+    with pytest.raises(gpu.LfiError):
+        ctx.fill_synthetic(SEED, 3, 17)
+    ctx.fill_synthetic_scene(SEED)
+    ctx.render("STD")
+    ctx.sync()
+    scene = ctx.download_views()
+    assert (scene[..., 3] == 255).all() and (scene != oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)).any()
+    ctx.focus_map()
+    ctx.sync()
+    assert len(np.unique(ctx.download_map(0)[..., 0])) >= 1
+    ctx.close()
