@@ -115,78 +115,98 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         ctx.set_params(hp)
         return ctx, hp
 
+    def guarded(section):
+        """One configuration's measurements; a failure (e.g. out of memory on a smaller device) is recorded, not raised."""
+        try:
+            section()
+        except Exception as e:
+            out[section.__name__ + "_error"] = f"{type(e).__name__}: {e}"
+
     # ---- config 2: the reference-layout (RGBA) output, STD, the non-tensor wavefront kernel ---------------------------------------
-    c2 = CONFIGS[2]
-    ctx, hp = make_ctx(c2)
-    if layout != "rgba":
-        ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
-        out["config2_ten_wm_rgba_views"] = entry(c2, ms, 64, ctx.last_kernel_name(), "views stored as RGBA planes (the reference's layout)")
-    ms = timed(ctx, lambda: ctx.render("STD"), iters)
-    out["config2_std"] = entry(c2, ms, 64, ctx.last_kernel_name(), "bit-exact STD (fp16 MFMA sum + exact fmaf chain inside the rounding band)")
-    ctx.set_variant("STD", "wave_m2_nt")
-    ms = timed(ctx, lambda: ctx.render("STD"), iters)
-    out["config2_std_exact_mfma"] = entry(c2, ms, 64, ctx.last_kernel_name(), "exact fp32 on v_mfma_f32_32x32x2_f32", flops_bound=True)
-    ctx.set_variant("STD", "vfma")
-    ms = timed(ctx, lambda: ctx.render("STD"), max(2, iters // 2), warm=1)
-    out["config2_std_valu"] = entry(c2, ms, 64, ctx.last_kernel_name(), "the non-tensor wavefront kernel: one pass over the inputs, v_pk_fma_f32 chains, weights in SGPRs", flops_bound=True)
-    ctx.close()
+    def config2():
+        c2 = CONFIGS[2]
+        ctx, hp = make_ctx(c2)
+        if layout != "rgba":
+            ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
+            out["config2_ten_wm_rgba_views"] = entry(c2, ms, 64, ctx.last_kernel_name(), "views stored as RGBA planes (the reference's layout)")
+        ms = timed(ctx, lambda: ctx.render("STD"), iters)
+        out["config2_std"] = entry(c2, ms, 64, ctx.last_kernel_name(), "bit-exact STD (fp16 MFMA sum + exact fmaf chain inside the rounding band)")
+        ctx.set_variant("STD", "wave_m2_nt")
+        ms = timed(ctx, lambda: ctx.render("STD"), iters)
+        out["config2_std_exact_mfma"] = entry(c2, ms, 64, ctx.last_kernel_name(), "exact fp32 on v_mfma_f32_32x32x2_f32", flops_bound=True)
+        ctx.set_variant("STD", "vfma")
+        ms = timed(ctx, lambda: ctx.render("STD"), max(2, iters // 2), warm=1)
+        out["config2_std_valu"] = entry(c2, ms, 64, ctx.last_kernel_name(), "the non-tensor wavefront kernel: one pass over the inputs, v_pk_fma_f32 chains, weights in SGPRs", flops_bound=True)
+        ctx.close()
+
+    guarded(config2)
 
     # ---- config 3: 15×15 @1080p, 45-view quilt -------------------------------------------------------------------------------------
-    c3 = CONFIGS[3]
-    ctx, hp = make_ctx(c3)
-    if layout != "rgba":
-        ctx.set_output_layout(layout)
-    ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
-    out["config3"] = entry(c3, ms, 45, ctx.last_kernel_name())
-    ctx.close()
+    def config3():
+        c3 = CONFIGS[3]
+        ctx, hp = make_ctx(c3)
+        if layout != "rgba":
+            ctx.set_output_layout(layout)
+        ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
+        out["config3"] = entry(c3, ms, 45, ctx.last_kernel_name())
+        ctx.close()
+
+    guarded(config3)
 
     # ---- config 4: 8×8 @4K, per rank (32 of 256 views) and whole (256 views on this GPU) -------------------------------------------
-    c4 = CONFIGS[4]
-    hp_r, v0, v1 = L.rank_params(c4["cols"], c4["rows"], c4["W"], c4["H"], c4["traj"], c4["focus"], 0.0, c4["effect"], c4["aspect"], 256, 8, 3)
-    ctx = L.Context(device_index)
-    ctx.set_grid(c4["cols"], c4["rows"], c4["W"], c4["H"])
-    ctx.fill_synthetic(SEED)
-    ctx.set_params(hp_r)
-    if layout != "rgba":
-        ctx.set_output_layout(layout)
-    ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
-    out["config4_rank"] = entry(c4, ms, v1 - v0, ctx.last_kernel_name(), f"rank 3 of 8: views [{v0},{v1}) of the 256-view trajectory")
-    hp_all = L.build_params(c4["cols"], c4["rows"], c4["W"], c4["H"], c4["traj"], c4["focus"], 0.0, c4["effect"], c4["aspect"], 256)
-    ctx.set_params(hp_all)
-    if layout != "rgba":
-        ctx.set_output_layout(layout)
-    ms = timed(ctx, lambda: ctx.render("TEN_WM"), max(2, iters // 2))
-    out["config4_whole_1gpu"] = entry(c4, ms, 256, ctx.last_kernel_name(), "the whole 256-view trajectory on one GPU (inputs read once)")
-    ctx.close()
+    def config4():
+        c4 = CONFIGS[4]
+        hp_r, v0, v1 = L.rank_params(c4["cols"], c4["rows"], c4["W"], c4["H"], c4["traj"], c4["focus"], 0.0, c4["effect"], c4["aspect"], 256, 8, 3)
+        ctx = L.Context(device_index)
+        ctx.set_grid(c4["cols"], c4["rows"], c4["W"], c4["H"])
+        ctx.fill_synthetic(SEED)
+        ctx.set_params(hp_r)
+        if layout != "rgba":
+            ctx.set_output_layout(layout)
+        ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
+        out["config4_rank"] = entry(c4, ms, v1 - v0, ctx.last_kernel_name(), f"rank 3 of 8: views [{v0},{v1}) of the 256-view trajectory")
+        hp_all = L.build_params(c4["cols"], c4["rows"], c4["W"], c4["H"], c4["traj"], c4["focus"], 0.0, c4["effect"], c4["aspect"], 256)
+        ctx.set_params(hp_all)
+        if layout != "rgba":
+            ctx.set_output_layout(layout)
+        ms = timed(ctx, lambda: ctx.render("TEN_WM"), max(2, iters // 2))
+        out["config4_whole_1gpu"] = entry(c4, ms, 256, ctx.last_kernel_name(), "the whole 256-view trajectory on one GPU (inputs read once)")
+        ctx.close()
+
+    guarded(config4)
 
     # ---- config 5: 15×15 @4K: fixed focus, and end to end = focus map (estimate + filter) + all-focus render, MFMA vs STD -----------
-    c5 = CONFIGS[5]
-    ctx, hp = make_ctx(c5)
-    if layout != "rgba":
-        ctx.set_output_layout(layout)
-    ms = timed(ctx, lambda: ctx.render("TEN_WM"), max(2, iters // 2))
-    out["config5_fixed_focus"] = entry(c5, ms, 64, ctx.last_kernel_name())
-    ctx.set_output_layout("rgba")
-    # the focus sweep on a STRUCTURED light field: a texture seen at a piecewise-constant focus inside
-    # [focus, focus + range], so that the estimated map is piecewise constant as on real scenes — on hash noise the map is noise and
-    # the all-focus gathers touch one cache line per pixel (measured: 17 ms instead of ≈2 ms), which no real input does
-    ctx.fill_synthetic_scene(SEED)
-    map_in = 4.0 * c5["W"] * c5["H"] * len(hp.focus_map_ids)          # the ≤32 sampled planes, read once by the estimate
-    map_io = 4.0 * c5["W"] * c5["H"] * 3                                # map 0 written + read, map 1 written
-    ms_map = timed(ctx, lambda: ctx.focus_map(), max(2, iters // 4), warm=1)
-    out["config5_focus_map"] = {"workload": "15x15 LF @3840x2160, focus map (estimate over 32 views x 32 candidates x 9 taps + filter)",
-                                "kernel": "focus_factored passes + focus_filter", "ms": ms_map,
-                                "algorithmic_bytes": map_in + map_io, "frac": (map_in + map_io) / ms_map / 1e6 / HBM_PEAK_GBS,
-                                "note": "bound by VALU issue / L2 (DESIGN.md 4.3), not HBM: the fraction is reported for completeness"}
-    for method in ("TEN_WM", "STD"):
-        ms_r = timed(ctx, lambda: ctx.render(method, all_focus=True), max(2, iters // 4), warm=1)
-        k = ctx.last_kernel_name()
-        ms_e = timed(ctx, lambda: (ctx.focus_map(), ctx.render(method, all_focus=True)), max(2, iters // 4), warm=1)
-        key = "config5_allfocus_" + method.lower()
-        out[key + "_render"] = entry(c5, ms_r, 64, k, "all-focus render from a resident focus map (structured light field)", flops_bound=(method == "STD"))
-        out[key + "_end_to_end"] = entry(c5, ms_e, 64, "focus map + " + k, "lfi_focus_map + all-focus render per iteration (-r 0.17)",
-                                         in_bytes_extra=map_in + map_io, flops_bound=(method == "STD"))
-    ctx.close()
+    def config5():
+        c5 = CONFIGS[5]
+        ctx, hp = make_ctx(c5)
+        if layout != "rgba":
+            ctx.set_output_layout(layout)
+        ms = timed(ctx, lambda: ctx.render("TEN_WM"), max(2, iters // 2))
+        out["config5_fixed_focus"] = entry(c5, ms, 64, ctx.last_kernel_name())
+        ctx.set_output_layout("rgba")
+        # the focus sweep on a STRUCTURED light field (SURVEY.md §8(d)): a texture seen at a piecewise-constant focus inside
+        # [focus, focus + range], so that the estimated map is piecewise constant as on real scenes — on hash noise the map is noise and
+        # the all-focus gathers touch one cache line per pixel (measured: 17 ms instead of ≈2 ms), which no real input does
+        ctx.fill_synthetic_scene(SEED)
+        map_in = 4.0 * c5["W"] * c5["H"] * len(hp.focus_map_ids)          # the ≤32 sampled planes, read once by the estimate
+        map_io = 4.0 * c5["W"] * c5["H"] * 3                                # map 0 written + read, map 1 written
+        ms_map = timed(ctx, lambda: ctx.focus_map(), max(2, iters // 4), warm=1)
+        out["config5_focus_map"] = {"workload": "15x15 LF @3840x2160, focus map (estimate over 32 views x 32 candidates x 9 taps + filter)",
+                                    "kernel": "focus_factored passes + focus_filter", "ms": ms_map,
+                                    "algorithmic_bytes": map_in + map_io, "frac": (map_in + map_io) / ms_map / 1e6 / HBM_PEAK_GBS,
+                                    "note": "bound by VALU issue / L2 (DESIGN.md 4.3), not HBM: the fraction is reported for completeness"}
+        for method in ("TEN_WM", "STD"):
+            ms_r = timed(ctx, lambda: ctx.render(method, all_focus=True), max(2, iters // 4), warm=1)
+            k = ctx.last_kernel_name()
+            ms_e = timed(ctx, lambda: (ctx.focus_map(), ctx.render(method, all_focus=True)), max(2, iters // 4), warm=1)
+            key = "config5_allfocus_" + method.lower()
+            out[key + "_render"] = entry(c5, ms_r, 64, k, "all-focus render from a resident focus map (structured light field)", flops_bound=(method == "STD"))
+            out[key + "_end_to_end"] = entry(c5, ms_e, 64, "focus map + " + k, "lfi_focus_map + all-focus render per iteration (-r 0.17)",
+                                             in_bytes_extra=map_in + map_io, flops_bound=(method == "STD"))
+        ctx.close()
+
+    guarded(config5)
+
     return out
 
 
@@ -430,7 +450,10 @@ def main() -> int:
     torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_also and args.config == 2 and args.shard == "views":
-            line["also"] = also_table(L, device_index, args.also_iters, args.layout)
+            try:
+                line["also"] = also_table(L, device_index, args.also_iters, args.layout)
+            except Exception as e:      # the headline line must come out whatever happens to the extra configurations
+                line["also"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
