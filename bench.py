@@ -129,6 +129,14 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         if layout != "rgba":
             ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
             out["config2_ten_wm_rgba_views"] = entry(c2, ms, 64, ctx.last_kernel_name(), "views stored as RGBA planes (the reference's layout)")
+            # the headline kernel with every launch walking the image in the same direction (what a single cold launch does): the
+            # default alternates the direction between consecutive launches, which re-reads part of the inputs from the Infinity Cache
+            ctx.set_output_layout(layout)
+            ctx.set_params(hp, flags=L.LFI_FLAG_SINGLE_SWEEP_DIRECTION)
+            ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
+            out["config2_ten_wm_single_sweep_direction"] = entry(c2, ms, 64, ctx.last_kernel_name(), "LFI_FLAG_SINGLE_SWEEP_DIRECTION: no Infinity Cache reuse between launches")
+            ctx.set_params(hp)
+            ctx.set_output_layout("rgba")
         ms = timed(ctx, lambda: ctx.render("STD"), iters)
         out["config2_std"] = entry(c2, ms, 64, ctx.last_kernel_name(), "bit-exact STD (fp16 MFMA sum + exact fmaf chain inside the rounding band)")
         ctx.set_variant("STD", "wave_m2_nt")
@@ -409,6 +417,8 @@ def main() -> int:
                        "view_layout": ("RGBA planes (the reference's)" if args.layout == "rgba" else
                                        "alpha-free byte planes [view][R,G,B][H][W] (opt-in, lfi_set_output_layout; alpha = 255 is re-created "
                                        "on download)"),
+                       "sweep": "consecutive launches walk the image in opposite directions (input rows read last are read first by the next "
+                                "launch: Infinity Cache reuse; LFI_FLAG_SINGLE_SWEEP_DIRECTION disables, timed in `also`)",
                        "inputs": ("resident in HBM before the timed region: RGBA planes + the derived planar alpha-free copy the kernel "
                                   "reads (built once per change of the inputs, outside every render: DESIGN.md 4.1)"
                                   if reads_planar else "resident in HBM before the timed region: RGBA planes"),

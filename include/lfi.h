@@ -57,7 +57,12 @@ enum {
     LFI_FLAG_UNIFIED_FOCUS_MAP = 1u,
     /* TEN_WM debug numerics: re-round the accumulator to fp16 after every 16-image batch, which reproduces the
      * reference's half-accumulator WMMA model (oracle model M16) instead of one final rounding */
-    LFI_FLAG_TEN_ROUND_PER_BATCH = 2u
+    LFI_FLAG_TEN_ROUND_PER_BATCH = 2u,
+    /* Fixed-focus launches over the planar input copy alternate their sweep direction from launch to launch, so that the input rows
+     * one launch read last — still in the 256 MB Infinity Cache — are the first the next launch reads (repeated renders of one light
+     * field: the reference's 100-launch loop, trajectory blocks, focus sweeps).  With this flag every launch walks the image in
+     * ascending order, as a single cold launch does.  Results are identical either way. */
+    LFI_FLAG_SINGLE_SWEEP_DIRECTION = 4u
 };
 
 #define LFI_MAX_IMAGES 256     /* MAX_IMAGES, src/kernels.cu:60 */

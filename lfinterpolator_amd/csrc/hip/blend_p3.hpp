@@ -58,7 +58,7 @@ __host__ __device__ constexpr int p3_octet_off(int o)
 // ABL (measurement builds only, LFI_P3_ABLATE): 0 = the kernel; 1 = no k-loop (DMA + barriers + stores of zeros); 2 = no DMA (the
 // k-loop runs on whatever LDS holds); 3 = no stores.  Outputs of ABL != 0 are garbage by construction.
 template <bool NT_STORE, int NCH, int ABL = 0>
-__global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes)
+__global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes, const int reverse)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[3 * P3_BUF_B + LFI_MAX_IMAGES * 8];
 
@@ -130,7 +130,8 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
         return pc;
     };
     // returns the number of DMA instructions issued by this wave (wave-uniform)
-    auto issue = [&](const int t, const int chunk, const int buf, const Pieces &pc) {
+    auto issue = [&](const int t_seq, const int chunk, const int buf, const Pieces &pc) {
+        const int t = reverse ? n_tiles - 1 - t_seq : t_seq; // odd launches walk the image backwards: see launch_p3
         const int ty = t / tiles_x;
         const int y = a.out_y0 + ty;
         const int x0 = (t - ty * tiles_x) * P3_TPX;
@@ -222,7 +223,8 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
     // epilogue of tile t: quantise (acc = S·2^-9), pack eight pixels per (view, channel), store; returns the number of store
     // instructions issued (wave-uniform)
     const uint32_t plane_b = uint32_t(a.out_rows) * uint32_t(a.views_pitch); // bytes of one byte plane (< 2^26·… checked on the host)
-    auto epilogue = [&](const int t, const int vw, const int nvalid) {
+    auto epilogue = [&](const int t_seq, const int vw, const int nvalid) {
+        const int t = reverse ? n_tiles - 1 - t_seq : t_seq;
         const int ty = t / tiles_x; // row inside the output window
         const int x0 = (t - ty * tiles_x) * P3_TPX;
         uint32_t hq[48]; // [(i·3 + channel)·4 + block pair]: two halves, 0x4000 | byte after the rounding-mode window

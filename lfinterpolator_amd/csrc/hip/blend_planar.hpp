@@ -186,7 +186,8 @@ __device__ __forceinline__ int store_tile_filtered(const KernelArgs &a, f32x16 (
 // pass when the image stack fits one chunk; the weight fragments are fetched per unit — or once per workgroup when there is a
 // single chunk and a single pass (config 2, every bench step).
 template <int MT, bool NT_STORE, bool STDF = false>
-__global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes, const int ring3)
+__global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes, const int ring3,
+                                                       const int reverse)
 {
     constexpr int KC = 64, VPP = MT * 32, TPX = 128;
     constexpr int W_DW = (KC / 8) * VPP * 4; // fp16 weight fragments [k-octet][view] × 16 B
@@ -245,7 +246,10 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
         }
         return pc;
     };
-    auto issue_pixels = [&](const int t, const int k0, const int pb, const Pieces &pc) {
+    // reverse: this launch walks the tile sequence backwards (consecutive launches alternate: Infinity Cache reuse, see launch_p3)
+    auto tile_of = [&](const int t_seq) { return reverse ? n_tiles - 1 - t_seq : t_seq; };
+    auto issue_pixels = [&](const int t_seq, const int k0, const int pb, const Pieces &pc) {
+        const int t = tile_of(t_seq);
         const int ty = t / tiles_x;
         const int y = a.out_y0 + ty;
         const int x0 = (t - ty * tiles_x) * TPX;
@@ -314,9 +318,9 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
 
             const uint8_t *col = reinterpret_cast<const uint8_t *>(lds + (buf3 == 2 ? THIRD_DW : buf3 * (PX_B / 4))) + wave * 32 + r + 8 * h * TPX;
             unit_ten_bytes<MT, TPX, KC, true>(col, w_buf, r, h, kc, acc3);
-            const int ty = t / tiles_x;
+            const int tt = tile_of(t), ty = tt / tiles_x;
             st2 = st1;
-            st1 = store_tile<false, MT, NT_STORE, false>(a, acc3, a.v0, ty, (t - ty * tiles_x) * TPX + wave * 32, r, h, oplane_px);
+            st1 = store_tile<false, MT, NT_STORE, false>(a, acc3, a.v0, ty, (tt - ty * tiles_x) * TPX + wave * 32, r, h, oplane_px);
             if(!next_in_flight)
                 break;
             t += G;
@@ -384,14 +388,14 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
         prev_stores = 0;
         if(k0 + KC >= a.k_pad) // last chunk of the tile's pass: epilogue
         {
-            const int ty = t / tiles_x;
+            const int tt = tile_of(t), ty = tt / tiles_x;
             if constexpr(STDF)
                 prev_stores = store_tile_filtered<MT, NT_STORE, KC, TPX>(
-                    a, acc, a.v0 + pass * VPP, ty, (t - ty * tiles_x) * TPX + wave * 32, lane, oplane_px,
+                    a, acc, a.v0 + pass * VPP, ty, (tt - ty * tiles_x) * TPX + wave * 32, lane, oplane_px,
                     reinterpret_cast<const uint8_t *>(lds) + pbuf * PX_B + wave * 32, reinterpret_cast<const uint16_t *>(w_buf), kc,
                     reinterpret_cast<uint16_t *>(lds + THIRD_DW + W_DW + OFF_DW) + wave * 128);
             else
-                prev_stores = store_tile<false, MT, NT_STORE, true>(a, acc, a.v0 + pass * VPP, ty, (t - ty * tiles_x) * TPX + wave * 32, r, h, oplane_px);
+                prev_stores = store_tile<false, MT, NT_STORE, true>(a, acc, a.v0 + pass * VPP, ty, (tt - ty * tiles_x) * TPX + wave * 32, r, h, oplane_px);
         }
         if(!have_next)
             break;

@@ -115,6 +115,7 @@ struct lfi_ctx
     size_t focus_ws_bytes = 0;
     int ten_variant = 0, std_variant = 0, focus_variant = 0;
     mutable const char *last_kernel = ""; // the blend kernel the last render launched (lfi_last_kernel_name)
+    mutable unsigned sweep_launches = 0;  // blend_p3 / blend_planar alternate their sweep direction from launch to launch
     float derived_build_ms = 0.0f;        // duration of the last planar_build (measured by lfi_prepare only)
     std::string err;
 };
@@ -256,6 +257,7 @@ dim3 pixel_grid(const lfi_ctx *c)
 
 hipStream_t stream_of(const lfi_ctx *c);
 void note_kernel(const lfi_ctx *c, const char *name);
+int next_sweep_direction(const lfi_ctx *c);
 uint32_t flags_of(const lfi_ctx *c);
 dim3 pixel_grid_of(const lfi_ctx *c);
 int cu_count_of(const lfi_ctx *c);
@@ -319,7 +321,7 @@ void launch_planar(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     const int passes = (a.v1 - a.v0 + 63) / 64;
     const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
     note_kernel(c, "blend_planar<TEN_WM>");
-    hipLaunchKernelGGL((lfi::blend_planar<2, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, RING3);
+    hipLaunchKernelGGL((lfi::blend_planar<2, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, RING3, next_sweep_direction(c));
 }
 
 // wave-private pipelines (blend_wave.hpp) where they apply — fixed focus, one K-chunk, one view pass — else blend_persist
@@ -352,7 +354,7 @@ void launch_std_filtered(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     const int passes = (a.v1 - a.v0 + 63) / 64;
     const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
     note_kernel(c, "blend_planar<STDF>");
-    hipLaunchKernelGGL((lfi::blend_planar<2, true, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, 0);
+    hipLaunchKernelGGL((lfi::blend_planar<2, true, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, 0, next_sweep_direction(c));
 }
 
 template <int PXL, int MT>
@@ -436,6 +438,16 @@ int check_render_args(lfi_ctx *c, int method, int v0, int v1)
 
 hipStream_t stream_of(const lfi_ctx *c) { return c->stream; }
 void note_kernel(const lfi_ctx *c, const char *name) { c->last_kernel = name; }
+// Consecutive launches over the same inputs (the reference's 100-launch loop, a trajectory streamed in blocks, a focus sweep) walk
+// the tiles in opposite directions: the input rows a launch read last are the ones the next launch reads first, so part of them
+// is still in the 256 MB Infinity Cache (config 2: −7 %, profiles/r02_p3_alternate.txt).  Same work, same bytes requested; fewer
+// of them come from HBM.  LFI_FLAG_SINGLE_SWEEP_DIRECTION turns it off (every launch ascending, as a cold launch behaves).
+int next_sweep_direction(const lfi_ctx *c)
+{
+    if(c->flags & LFI_FLAG_SINGLE_SWEEP_DIRECTION)
+        return 0;
+    return int(c->sweep_launches++ & 1u);
+}
 uint32_t flags_of(const lfi_ctx *c) { return c->flags; }
 dim3 pixel_grid_of(const lfi_ctx *c) { return pixel_grid(c); }
 int cu_count_of(const lfi_ctx *c) { return c->cu_count; }
@@ -522,7 +534,7 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
     if(ablate >= 1 && ablate <= 3 && (nch == 1 || nch == 4) && a_in.v1 - a_in.v0 <= 64)
     {
         note_kernel(c, "blend_p3<ABLATION>");
-#define LFI_P3_ABL(N, A) hipLaunchKernelGGL((lfi::blend_p3<true, N, A>), grid, block, 0, stream_of(c), a_in, tiles_x, n_tiles, 1)
+#define LFI_P3_ABL(N, A) hipLaunchKernelGGL((lfi::blend_p3<true, N, A>), grid, block, 0, stream_of(c), a_in, tiles_x, n_tiles, 1, 0)
         if(nch == 1)
         {
             if(ablate == 1) LFI_P3_ABL(1, 1); else if(ablate == 2) LFI_P3_ABL(1, 2); else LFI_P3_ABL(1, 3);
@@ -534,11 +546,12 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
 #undef LFI_P3_ABL
         return;
     }
+    const int reverse = next_sweep_direction(c);
     if(nch == 1)
     {
         // one chunk of images: every 64-view pass of a tile reads the same LDS-resident pixels (inputs fetched once per launch)
         const int passes = (a_in.v1 - a_in.v0 + 63) / 64;
-        hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a_in, tiles_x, n_tiles, passes);
+        hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a_in, tiles_x, n_tiles, passes, reverse);
         return;
     }
     // several chunks: one launch per 64 views (a workgroup's four waves take 16 views each)
@@ -549,9 +562,9 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
         a.v1 = std::min(v0 + 64, a_in.v1);
         switch(nch)
         {
-            case 2: hipLaunchKernelGGL((lfi::blend_p3<true, 2>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1); break;
-            case 3: hipLaunchKernelGGL((lfi::blend_p3<true, 3>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1); break;
-            default: hipLaunchKernelGGL((lfi::blend_p3<true, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1); break;
+            case 2: hipLaunchKernelGGL((lfi::blend_p3<true, 2>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse); break;
+            case 3: hipLaunchKernelGGL((lfi::blend_p3<true, 3>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse); break;
+            default: hipLaunchKernelGGL((lfi::blend_p3<true, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse); break;
         }
     }
 }

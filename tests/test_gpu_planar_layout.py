@@ -85,6 +85,14 @@ def test_ragged_shapes_planar_equals_rgba(shape, gpu, oracle_c):
     got = ctx.download_views()
     assert np.abs(got.astype(int) - m16.astype(int)).max() <= TEN_TOL_LSB
     assert (got == want).all(), int((got != want).sum())
+    # consecutive launches walk the image in opposite directions (Infinity Cache reuse): same bytes, with and without the alternation
+    for flags in (0, gpu.LFI_FLAG_SINGLE_SWEEP_DIRECTION):
+        ctx.set_params(hp, flags)
+        for _ in range(3):
+            ctx.render("TEN_WM")
+            ctx.sync()
+            assert (ctx.download_views() == want).all()
+    ctx.set_params(hp)
     # a second launch over a sub-range leaves the other views alone and reproduces its own
     v0, v1 = V // 3, max(V // 3 + 1, (2 * V) // 3)
     ctx.render("TEN_WM", v0=v0, v1=v1)
