@@ -1,0 +1,137 @@
+"""GPU (-m gpu): all-focus renders over STRUCTURED focus maps (uploaded, not estimated from noise): rows of one level, blocks that
+start and end off the 128-pixel tile grid, level boundaries on tile edges, per-pixel noise — the shapes real maps have (32 candidate
+levels, median-filtered), which the maps estimated from the suite's random light fields do not.
+
+The reference warps every pixel by its own focus value, (int)fma(f, offset, coord) then clamp-to-edge (src/kernels.cu:78-82, :125).
+Bit-exact against the oracle for STD, within the one-LSB contract for TEN_WM, in both view layouts, for view ranges and row bands."""
+import numpy as np
+import pytest
+
+from conftest import SEED
+
+pytestmark = pytest.mark.gpu
+
+TEN_TOL_LSB = 1
+
+
+def _map_rgba(levels):
+    m = np.zeros(levels.shape + (4,), dtype=np.uint8)
+    m[..., 0] = levels
+    m[..., 1] = levels
+    m[..., 2] = levels
+    m[..., 3] = 255
+    return m
+
+
+def _structured_levels(H, W, rng, noise=0.0):
+    """rows of constant level, blocks that start and end off the 128-pixel tile grid, a sprinkle of single-pixel outliers"""
+    lv = np.zeros((H, W), dtype=np.uint8)
+    for y in range(H):
+        kind = y % 4
+        if kind == 0:                      # the whole row one level: every tile uniform
+            lv[y] = rng.integers(0, 256)
+        elif kind == 1:                    # blocks of 90–400 pixels
+            x = 0
+            while x < W:
+                w = int(rng.integers(90, 400))
+                lv[y, x:x + w] = rng.integers(0, 256)
+                x += w
+        elif kind == 2:                    # two levels, the boundary exactly on a tile edge (if the row is wide enough)
+            lv[y] = rng.integers(0, 256)
+            lv[y, 128:] = rng.integers(0, 256)
+        else:                              # per-pixel noise: no uniform tile
+            lv[y] = rng.integers(0, 256, size=W)
+    if noise > 0:
+        mask = rng.random((H, W)) < noise
+        lv[mask] = rng.integers(0, 256, size=int(mask.sum()))
+    return lv
+
+
+def _ctx(gpu, cols, rows, W, H, hp, lf, flags=0, layout="rgba"):
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.upload_grid(lf)
+    ctx.set_params(hp, flags)
+    ctx.set_output_layout(layout)
+    return ctx
+
+
+CASES = [
+    # cols, rows, W, H, V, trajectory, focus, range, effect, aspect
+    (8, 8, 300, 16, 5, "0,0,1,1", 0.05, 0.4, 3.0, 1.783),
+    (15, 15, 520, 8, 3, "0.071,0.071,0.93,0.93", -0.2, 0.9, 7.0, 2.02),     # four chunks of images; offsets beyond the borders
+    (3, 3, 100, 9, 4, "0,0,1,1", 0.0, 1.5, 1.0, 1.0),                          # one ragged tile per row; level 0 is f = 0 exactly
+    (8, 8, 1000, 4, 33, "0.5,0.5,0.5,0.5", 0.3, -0.6, 3.0, 1.5),               # negative range; two view passes
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c[:5])))
+def test_structured_maps_match_the_oracle(case, gpu, oracle_c):
+    cols, rows, W, H, V, traj, focus, rng_, effect, aspect = case
+    hp = gpu.build_params(cols, rows, W, H, traj, focus, rng_, effect, aspect, V)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, SEED)
+    rng = np.random.default_rng(7)
+    maps = [_map_rgba(_structured_levels(H, W, rng, noise=0.002)), _map_rgba(_structured_levels(H, W, rng))]
+    want_std = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, all_focus=True, map_plane=maps[1], focus=hp.focus, rng=hp.range, threads=8)
+    want_ten = oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, all_focus=True, map_plane=maps[0], focus=hp.focus, rng=hp.range, threads=8)
+    for flags in (0, gpu.LFI_FLAG_SINGLE_SWEEP_DIRECTION):
+        ctx = _ctx(gpu, cols, rows, W, H, hp, lf, flags)
+        for k in (0, 1):
+            ctx.upload_map(k, maps[k])
+        ctx.render("STD", all_focus=True)          # reads map 1 (src/kernels.cu:326)
+        ctx.sync()
+        std = ctx.download_views()
+        ctx.render("TEN_WM", all_focus=True)       # reads map 0 (src/kernels.cu:430)
+        ctx.sync()
+        ten = ctx.download_views()
+        assert (std == want_std).all(), (flags, int((std != want_std).sum()))
+        assert np.abs(ten.astype(int) - want_ten.astype(int)).max() <= TEN_TOL_LSB, flags
+        # a view range, and the planar view layout (RGBA kernel + conversion)
+        ctx.render("TEN_WM", all_focus=True, v0=V // 2, v1=V // 2 + 1)
+        ctx.sync()
+        assert (ctx.download_views() == ten).all()
+        ctx.set_output_layout("planar")
+        ctx.render("TEN_WM", all_focus=True)
+        ctx.sync()
+        assert (ctx.download_views() == ten).all()
+        ctx.render("STD", all_focus=True)
+        ctx.sync()
+        assert (ctx.download_views() == std).all()
+        ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_structured_map_row_bands(world, gpu, oracle_c):
+    """Row-band sharding of an all-focus render from a structured map: every band gives its rows of the full render."""
+    cols = rows = 8
+    W, H, V = 260, 48, 6
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.04, 0.2, 3.0, 1.783, V)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, SEED)
+    rng = np.random.default_rng(3)
+    m = _map_rgba(_structured_levels(H, W, rng))
+    full = _ctx(gpu, cols, rows, W, H, hp, lf)
+    for k in (0, 1):
+        full.upload_map(k, m)
+    want = {}
+    for method in ("STD", "TEN_WM"):
+        full.render(method, all_focus=True)
+        full.sync()
+        want[method] = full.download_views()
+    full.close()
+    for method in ("STD", "TEN_WM"):
+        got = np.zeros_like(want[method])
+        for rank in range(world):
+            band = gpu.row_band(H, world, rank)
+            in_rows = gpu.input_rows_all_focus(band, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, H)
+            ctx = gpu.Context(0)
+            ctx.set_grid(cols, rows, W, H)
+            ctx.set_row_window(band[0], band[1], in_rows[0], in_rows[1])
+            ctx.fill_synthetic(SEED)
+            ctx.set_params(hp)
+            for k in (0, 1):
+                ctx.upload_map(k, m)
+            ctx.render(method, all_focus=True)
+            ctx.sync()
+            got |= ctx.download_views()
+            ctx.close()
+        assert (got == want[method]).all(), method
