@@ -52,14 +52,31 @@ __host__ __device__ constexpr int p3_octet_off(int o)
 
 #define LFI_P3_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void p3_for_each_chunk(F &&f)
+{
+    if constexpr(I < N)
+    {
+        f(std::integral_constant<int, I>{});
+        p3_for_each_chunk<N, I + 1>(f);
+    }
+}
+
 // planar views: plane (view, channel) at ((view·3 + channel)·rows)·pitch, pixel x of row y at y·pitch + x
 // view_passes > 1 (more than 64 views; NCH == 1 only — the host splits other launches): the tile stays in LDS for every pass, the
 // weight fragments of the next pass are fetched while the current one computes.
 // ABL (measurement builds only, LFI_P3_ABLATE): 0 = the kernel; 1 = no k-loop (DMA + barriers + stores of zeros); 2 = no DMA (the
 // k-loop runs on whatever LDS holds); 3 = no stores.  Outputs of ABL != 0 are garbage by construction.
-template <bool NT_STORE, int NCH, int ABL = 0>
-__global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes, const int reverse)
+// VG: groups of 16 views per wave.  1: four waves per workgroup, two waves per SIMD (memory-bound launches: one chunk of images).
+// 2: TWO waves per workgroup, 32 views each — the pixel operand of a block (LDS read + v_perm) is built once for two MFMAs, and the
+// kernel needs more than 256 registers (192 accumulators), which pins one wave to each SIMD: two workgroups per CU as before, each
+// wave alone on its SIMD.  For launches of several chunks, where the k-loop (not the DMA) sets the pace with four waves.
+template <bool NT_STORE, int NCH, int ABL = 0, int VG = 1>
+__global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes, const int reverse)
 {
+    static_assert(VG == 1 || VG == 2, "16 or 32 views per wave");
+    constexpr int NW = 4 / VG;  // waves per workgroup
+    constexpr int OPW = 8 / NW; // octets of a chunk (and channel) each wave fetches
     __shared__ __attribute__((aligned(16))) uint8_t lds[3 * P3_BUF_B + LFI_MAX_IMAGES * 8];
 
     const int lane = threadIdx.x & 63;
@@ -69,7 +86,7 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr_t)lds)));
     const size_t shift_stride = (size_t)a.in_rows * a.planar_pitch; // one byte plane of the planar inputs
     int2 *off_table = reinterpret_cast<int2 *>(lds + 3 * P3_BUF_B);
-    for(int g = threadIdx.x; g < a.n_images; g += 256)
+    for(int g = threadIdx.x; g < a.n_images; g += 64 * NW)
     {
         const lfi_int2 o = a.focused[g];
         off_table[g] = make_int2(o.x, o.y);
@@ -77,25 +94,29 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
 
     // this wave's 16 views of a pass (views v0 + 64·pass + 16·wave …): all their weights, as MFMA A fragments (k-step s = images
     // 32s … 32s+31)
-    const int vw0 = a.v0 + 16 * wave;
-    auto load_weights = [&](const int pass, half8 (&w_out)[2 * NCH]) {
+    const int vw0 = a.v0 + 16 * VG * wave;
+    auto load_weights = [&](const int pass, half8 (&w_out)[VG][2 * NCH]) {
 #pragma unroll
-        for(int s = 0; s < 2 * NCH; s++)
-        {
-            const int k = 32 * s + 8 * kg;
-            u32x4 w = {0u, 0u, 0u, 0u};
-            if(k < a.k_pad) // rows are k_pad halves long (a multiple of 16): nothing is read across a row's end
-                w = *reinterpret_cast<const u32x4 *>(a.w16s + (size_t)(vw0 + 64 * pass + n) * a.k_pad + k);
-            w_out[s] = __builtin_bit_cast(half8, w);
-        }
+        for(int vg = 0; vg < VG; vg++)
+#pragma unroll
+            for(int s = 0; s < 2 * NCH; s++)
+            {
+                const int k = 32 * s + 8 * kg;
+                u32x4 w = {0u, 0u, 0u, 0u};
+                if(k < a.k_pad) // rows are k_pad halves long (a multiple of 16): nothing is read across a row's end
+                    w = *reinterpret_cast<const u32x4 *>(a.w16s + (size_t)(vw0 + 16 * vg + 64 * pass + n) * a.k_pad + k);
+                w_out[vg][s] = __builtin_bit_cast(half8, w);
+            }
     };
-    half8 wreg[2 * NCH];
+    half8 wreg[VG][2 * NCH];
     load_weights(0, wreg);
     // the loads above are the only vector loads the compiler knows about: make it wait for them HERE, before any LDS-DMA is in
     // flight, instead of with a vmcnt(0) in front of the first MFMA (which would also drain the pipeline's first three tiles)
 #pragma unroll
-    for(int s = 0; s < 2 * NCH; s++)
-        asm volatile("" : "+v"(wreg[s]));
+    for(int vg = 0; vg < VG; vg++)
+#pragma unroll
+        for(int s = 0; s < 2 * NCH; s++)
+            asm volatile("" : "+v"(wreg[vg][s]));
 
     const int G = gridDim.x;
     const int t0 = int(xcd_contiguous(blockIdx.x, gridDim.x));
@@ -109,16 +130,16 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
     // vector arithmetic in the loop.  Per octet a lane keeps its image's integer offsets and its image's distance from the base.
     struct Pieces
     {
-        int ox[2], oy[2];
-        uint32_t img_off[2]; // (this lane's image − the octet's first image) · 12 planes, in bytes (< 2^32: checked on the host)
-        int g_base[2];       // the octet's first image (wave-uniform), clamped to the last image
+        int ox[OPW], oy[OPW];
+        uint32_t img_off[OPW]; // (this lane's image − the octet's first image) · 12 planes, in bytes (< 2^32: checked on the host)
+        int g_base[OPW];       // the octet's first image (wave-uniform), clamped to the last image
     };
     auto lookup = [&](const int chunk) {
         Pieces pc;
 #pragma unroll
-        for(int o2 = 0; o2 < 2; o2++)
+        for(int o2 = 0; o2 < OPW; o2++)
         {
-            const int octet = wave + 4 * o2;
+            const int octet = wave + NW * o2;
             const int g_base = min(P3_KC * chunk + 8 * octet, a.n_images - 1);
             const int dg = min(lane >> 3, a.n_images - 1 - g_base); // padded images (zero weights) re-read the last one
             const int2 o = off_table[g_base + dg];
@@ -139,9 +160,9 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
         const uint32_t dst = lds_base + uint32_t(buf) * P3_BUF_B;
         int count = 0;
 #pragma unroll
-        for(int o2 = 0; o2 < 2; o2++)
+        for(int o2 = 0; o2 < OPW; o2++)
         {
-            const int octet = wave + 4 * o2;
+            const int octet = wave + NW * o2;
             if(8 * octet >= kc)
                 continue; // wave-uniform: the chunk is shorter (its length is a multiple of 16)
             // the run starts at pixel x0 + ox: dword aligned in shift copy (x0 + ox + padx) & 3; the padding exceeds every offset
@@ -165,17 +186,22 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
         return count;
     };
 
-    f32x4 acc[8][3]; // [block = pixel 8n + blk][channel]: views 4kg + i
+    f32x4 acc[VG][8][3]; // [view group][block = pixel 8n + blk][channel]: views 16·group + 4kg + i
+    auto clear_acc = [&] {
 #pragma unroll
-    for(int b = 0; b < 8; b++)
+        for(int vg = 0; vg < VG; vg++)
 #pragma unroll
-        for(int ch = 0; ch < 3; ch++)
-            acc[b][ch] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for(int b = 0; b < 8; b++)
+#pragma unroll
+                for(int ch = 0; ch < 3; ch++)
+                    acc[vg][b][ch] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    };
+    clear_acc();
 
     // k-loop of one unit from buffer `buf`: wk = the chunk's two weight fragments
     const uint32_t lane_px = uint32_t(1024 * kg + 128 * ((kg + 1) >> 1) + 8 * n); // p3_octet_off(kg) + this lane's 8 pixels
     // `fresh` (one-chunk launches): the first k-step takes a zero C operand, so the accumulators are never cleared
-    auto compute = [&](const half8 (&wk)[2], const int buf, const int kc, auto fresh_tag) {
+    auto compute = [&](const half8 (&wk)[VG][2], const int buf, const int kc, auto fresh_tag) {
         constexpr bool fresh = decltype(fresh_tag)::value;
         if constexpr(ABL == 1)
             return;
@@ -215,7 +241,10 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
                     // [15:0] = byte (b & 3) of image 2q, [31:16] = the same byte of image 2q + 1: two fp16 subnormals
                     bf[q] = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | uint32_t(b & 3) | (uint32_t(4 + (b & 3)) << 16));
                 }
-                acc[b][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[ks], __builtin_bit_cast(half8, bf), (ks == 0 && fresh) ? zero4 : acc[b][ch], 0, 0, 0);
+#pragma unroll
+                for(int vg = 0; vg < VG; vg++)
+                    acc[vg][b][ch] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[vg][ks], __builtin_bit_cast(half8, bf), (ks == 0 && fresh) ? zero4 : acc[vg][b][ch], 0, 0, 0);
             }
         }
     };
@@ -223,7 +252,7 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
     // epilogue of tile t: quantise (acc = S·2^-9), pack eight pixels per (view, channel), store; returns the number of store
     // instructions issued (wave-uniform)
     const uint32_t plane_b = uint32_t(a.out_rows) * uint32_t(a.views_pitch); // bytes of one byte plane (< 2^26·… checked on the host)
-    auto epilogue = [&](const int t_seq, const int vw, const int nvalid) {
+    auto epilogue = [&](const f32x4 (&acc)[8][3], const int t_seq, const int vw, const int nvalid) {
         const int t = reverse ? n_tiles - 1 - t_seq : t_seq;
         const int ty = t / tiles_x; // row inside the output window
         const int x0 = (t - ty * tiles_x) * P3_TPX;
@@ -314,15 +343,26 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
         if constexpr(NCH > 1)
             pc = lookup(ic);
     }
-    int ct = t0, cc = 0, buf = 0; // compute cursor
-    int st1 = 0, st2 = 0;         // store instructions of the previous unit's epilogue and of the one before
-    while(true)
-    {
+    int ct = t0, buf = 0; // compute cursor (the chunk is the compile-time argument of `unit`)
+    int st1 = 0, st2 = 0; // store instructions of the previous unit's epilogue and of the one before
+    // One unit; the chunk index is a compile-time constant (the loop below is unrolled over the chunks of a tile), so the chunk's
+    // weight fragments are registers named at compile time — a runtime index would put them into scratch, and wave-uniform selects
+    // over all chunks cost a copy of the fragments.  Returns false after the last unit of this workgroup.
+    auto unit = [&](auto cc_tag) -> bool {
+        constexpr int cc = decltype(cc_tag)::value;
         // VMEM operations of this wave younger than the current unit's DMA: stores(u−2), DMA(u+1), stores(u−1) — they may stay in
         // flight; vmcnt retires in order, so "at most that many outstanding" means the current unit's pieces have landed
         const int allowed = st2 + (have1 ? nd1 : 0) + st1;
-        switch(min(allowed, 31) >> 2)
+        switch(min(allowed, 63) >> 2) // (VG 2: up to 24 + 12 + 24)
         {
+            case 15: LFI_P3_WAIT(60); break;
+            case 14: LFI_P3_WAIT(56); break;
+            case 13: LFI_P3_WAIT(52); break;
+            case 12: LFI_P3_WAIT(48); break;
+            case 11: LFI_P3_WAIT(44); break;
+            case 10: LFI_P3_WAIT(40); break;
+            case 9: LFI_P3_WAIT(36); break;
+            case 8: LFI_P3_WAIT(32); break;
             case 7: LFI_P3_WAIT(28); break;
             case 6: LFI_P3_WAIT(24); break;
             case 5: LFI_P3_WAIT(20); break;
@@ -354,62 +394,74 @@ __global__ void __launch_bounds__(256, 2) blend_p3(const KernelArgs a, const int
             // valid as long as they count only operations that were certainly issued (the stores and the DMA, not these loads).
             for(int pass = 0; pass < view_passes; pass++)
             {
-                half8 wnext[2];
+                half8 wnext[VG][2];
                 if(view_passes > 1)
                     load_weights(pass + 1 == view_passes ? 0 : pass + 1, wnext);
                 const int vw = vw0 + 64 * pass;
-                const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw, 16)); // ≤ 0: nothing to do for this wave
+                const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw, 16 * VG)); // ≤ 0: nothing to do for this wave
                 if(nvalid > 0)
                 {
-                    const half8 wk[2] = {wreg[0], wreg[1]};
+                    half8 wk[VG][2];
+#pragma unroll
+                    for(int vg = 0; vg < VG; vg++)
+                    {
+                        wk[vg][0] = wreg[vg][0];
+                        wk[vg][1] = wreg[vg][1];
+                    }
                     compute(wk, buf, kc, std::true_type{});
-                    st1 += epilogue(ct, vw, nvalid);
+#pragma unroll
+                    for(int vg = 0; vg < VG; vg++)
+                        if(nvalid > 16 * vg) // wave-uniform
+                            st1 += epilogue(acc[vg], ct, vw + 16 * vg, min(nvalid - 16 * vg, 16));
                 }
                 if(view_passes > 1)
                 {
-                    wreg[0] = wnext[0];
-                    wreg[1] = wnext[1];
+#pragma unroll
+                    for(int vg = 0; vg < VG; vg++)
+                    {
+                        wreg[vg][0] = wnext[vg][0];
+                        wreg[vg][1] = wnext[vg][1];
+                    }
                 }
             }
         }
         else
         {
-            const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw0, 16)); // ≤ 0: this wave only helps with the DMA
+            const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw0, 16 * VG)); // ≤ 0: this wave only helps with the DMA
             if(nvalid > 0)
             {
-                // the chunk's fragments by wave-uniform selects over compile-time register indices (a runtime index would put
-                // wreg into scratch, and scratch accesses would enter the vmcnt queue the waits above count)
-                half8 wk[2] = {wreg[0], wreg[1]};
+                half8 wk[VG][2];
 #pragma unroll
-                for(int c = 1; c < NCH; c++)
-                    if(cc == c)
-                    {
-                        wk[0] = wreg[2 * c];
-                        wk[1] = wreg[2 * c + 1];
-                    }
-                compute(wk, buf, kc, std::false_type{}); // (a second, zero-C copy of the k-loop for chunk 0 costs more registers than the clear)
-                if(cc == NCH - 1)
+                for(int vg = 0; vg < VG; vg++)
                 {
-                    st1 = epilogue(ct, vw0, nvalid);
+                    wk[vg][0] = wreg[vg][2 * cc];
+                    wk[vg][1] = wreg[vg][2 * cc + 1];
+                }
+                compute(wk, buf, kc, std::integral_constant<bool, cc == 0>{}); // chunk 0 starts from a zero C operand: no clears
+                if constexpr(cc == NCH - 1)
+                {
 #pragma unroll
-                    for(int b = 0; b < 8; b++)
-#pragma unroll
-                        for(int ch = 0; ch < 3; ch++)
-                            acc[b][ch] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    for(int vg = 0; vg < VG; vg++)
+                        if(nvalid > 16 * vg) // wave-uniform
+                            st1 += epilogue(acc[vg], ct, vw0 + 16 * vg, min(nvalid - 16 * vg, 16));
                 }
             }
         }
         if(!have1)
-            break;
-        if(++cc == NCH)
-        {
-            cc = 0;
+            return false;
+        if constexpr(cc == NCH - 1)
             ct += G;
-        }
         buf = buf == 2 ? 0 : buf + 1;
         have1 = have2;
         nd1 = nd2;
-    }
+        return true;
+    };
+    bool more = true;
+    while(more)
+        p3_for_each_chunk<NCH>([&](auto cc_tag) {
+            if(more)
+                more = unit(cc_tag);
+        });
 }
 
 // ---- layout conversions for the planar view layout ------------------------------------------------------------------------------

@@ -552,7 +552,7 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
     if(ablate >= 1 && ablate <= 3 && (nch == 1 || nch == 4) && a_in.v1 - a_in.v0 <= 64)
     {
         note_kernel(c, "blend_p3<ABLATION>");
-#define LFI_P3_ABL(N, A) hipLaunchKernelGGL((lfi::blend_p3<true, N, A>), grid, block, 0, stream_of(c), a_in, tiles_x, n_tiles, 1, 0)
+#define LFI_P3_ABL(N, A) hipLaunchKernelGGL((lfi::blend_p3<true, N, A, (N == 1 ? 1 : 2)>), grid, dim3(N == 1 ? 256 : 128), 0, stream_of(c), a_in, tiles_x, n_tiles, 1, 0)
         if(nch == 1)
         {
             if(ablate == 1) LFI_P3_ABL(1, 1); else if(ablate == 2) LFI_P3_ABL(1, 2); else LFI_P3_ABL(1, 3);
@@ -565,25 +565,42 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
         return;
     }
     const int reverse = next_sweep_direction(c);
+    // Views per wave: 16 (four waves per workgroup, two per SIMD) when the launch is paced by its memory pipeline — one chunk of
+    // images — and 32 (two waves per workgroup, one per SIMD, the pixel operand built once for two MFMAs) when several chunks make the
+    // k-loop the pacer (15×15 grids: −13 % at 4K, profiles/r02_p3_vg.txt).  LFI_P3_VG = 1 / 2 forces either (measurements only).
+    static const int vg_env = [] {
+        const char *e = std::getenv("LFI_P3_VG");
+        return e ? std::atoi(e) : 0;
+    }();
+    const dim3 block2(128);
     if(nch == 1)
     {
         // one chunk of images: every 64-view pass of a tile reads the same LDS-resident pixels (inputs fetched once per launch)
         const int passes = (a_in.v1 - a_in.v0 + 63) / 64;
-        hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a_in, tiles_x, n_tiles, passes, reverse);
+        if(vg_env == 2)
+            hipLaunchKernelGGL((lfi::blend_p3<true, 1, 0, 2>), grid, block2, 0, stream_of(c), a_in, tiles_x, n_tiles, passes, reverse);
+        else
+            hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a_in, tiles_x, n_tiles, passes, reverse);
         return;
     }
-    // several chunks: one launch per 64 views (a workgroup's four waves take 16 views each)
+    // several chunks: one launch per 64 views
     for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 64)
     {
         KernelArgs a = a_in;
         a.v0 = v0;
         a.v1 = std::min(v0 + 64, a_in.v1);
+#define LFI_P3_LAUNCH(N)                                                                                                                        \
+    if(vg_env == 1)                                                                                                                             \
+        hipLaunchKernelGGL((lfi::blend_p3<true, N, 0, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse);                        \
+    else                                                                                                                                        \
+        hipLaunchKernelGGL((lfi::blend_p3<true, N, 0, 2>), grid, block2, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse)
         switch(nch)
         {
-            case 2: hipLaunchKernelGGL((lfi::blend_p3<true, 2>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse); break;
-            case 3: hipLaunchKernelGGL((lfi::blend_p3<true, 3>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse); break;
-            default: hipLaunchKernelGGL((lfi::blend_p3<true, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse); break;
+            case 2: LFI_P3_LAUNCH(2); break;
+            case 3: LFI_P3_LAUNCH(3); break;
+            default: LFI_P3_LAUNCH(4); break;
         }
+#undef LFI_P3_LAUNCH
     }
 }
 

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string>
 
 #define CK(x) do { hipError_t e = (x); if(e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while(0)
 
@@ -39,7 +40,7 @@ __device__ __forceinline__ void xcd_range(uint32_t b, uint32_t nb, uint32_t n_ti
     end = hi;
 }
 
-enum { OUT_RGBA = 0, OUT_PLANAR = 1, OUT_RGB24 = 2, OUT_RGB24_X3 = 3, OUT_NONE = 4 };
+enum { OUT_RGBA = 0, OUT_PLANAR = 1, OUT_RGB24 = 2, OUT_RGB24_X3 = 3, OUT_NONE = 4, OUT_PLANAR64 = 5 };
 
 // persistent: grid = 2 x CUs x ..., tiles t, t+G, ...   MAP: 0 = batches of G tiles split over the XCDs (blend_planar today), 1 = xcd_range
 // wider tiles: runs of TW bytes per (image, channel) and per (view, channel) plane row — does the memory system prefer longer runs?
@@ -142,6 +143,22 @@ __global__ void __launch_bounds__(256) k_tile(const uint8_t *__restrict__ planar
                     if(NT) __builtin_nontemporal_store(val, p); else *p = val;
                 }
         }
+        else if(OUT == OUT_PLANAR64)
+        {
+            // a wave = 64 pixels x 32 views: 4 bytes per lane, 16 lanes = 64 B of one plane row (half a line), four rows per instruction
+            const int c = lane & 15, kg = lane >> 4, ph = wave & 1, vh = wave >> 1;
+#pragma unroll
+            for(int vg = 0; vg < 2; vg++)
+#pragma unroll
+                for(int i = 0; i < 4; i++)
+#pragma unroll
+                    for(int ch = 0; ch < 3; ch++)
+                    {
+                        const int v = 32 * vh + 16 * vg + 4 * kg + i;
+                        uint32_t *p = reinterpret_cast<uint32_t *>(views + ((size_t)v * 3 + ch) * PLANE + (size_t)y * W + x0 + 64 * ph + 4 * c);
+                        if(NT) __builtin_nontemporal_store(acc[0] + i + vg, p); else *p = acc[0] + i + vg;
+                    }
+        }
         else if(OUT == OUT_RGB24)
         {
             const int c = lane & 15, kg = lane >> 4;
@@ -216,7 +233,7 @@ float run_wide(const char *name, int wgs_per_cu)
     return ms;
 }
 
-int main()
+int main(int argc, char **argv)
 {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     g_cus = prop.multiProcessorCount;
@@ -230,6 +247,22 @@ int main()
     CK(hipMalloc(&planar, planar_bytes)); CK(hipMalloc(&g_views, PLANE * 4 * NV));
     CK(hipMemset(planar, 1, planar_bytes)); CK(hipMemset(g_views, 2, PLANE * 4 * NV));
     g_planar = planar;
+    if(argc > 1 && std::string(argv[1]) == "p64")
+    {
+        // half-line stores (a wave = 64 pixels x 32 views) against whole-line stores, in ordinary and in uncached device memory
+        uint8_t *cached = g_views, *uncached = nullptr;
+        CK(hipExtMallocWithFlags(reinterpret_cast<void **>(&uncached), PLANE * 4 * NV, hipDeviceMallocUncached));
+        for(int round = 0; round < 3; round++)
+            for(int mem = 0; mem < 2; mem++)
+            {
+                g_views = mem ? uncached : cached;
+                printf("-- round %d, views in %s memory\n", round, mem ? "uncached" : "ordinary");
+                run<OUT_PLANAR, true, 0>("planar out, 128 B per row and instruction, nt", 2);
+                run<OUT_PLANAR64, true, 0>("planar out, 64 B per row and instruction, nt", 2);
+                run<OUT_PLANAR64, false, 0>("planar out, 64 B per row and instruction, plain", 2);
+            }
+        return 0;
+    }
     printf("planar copy %.2f GB, pitch %d, padx %d, %d CUs\n", planar_bytes / 1e9, g_pitch, g_padx, g_cus);
     for(int round = 0; round < 2; round++)
         for(int wpc : {2, 4, 8})
