@@ -120,14 +120,14 @@ __device__ __forceinline__ int store_tile_filtered(const KernelArgs &a, f32x16 (
                 if(vrow >= nvalid) // wave-uniform
                     continue;
                 const bool valid = lane_x_ok && vrow + 4 * h < nvalid;
-                uint32_t bits[3];
+                const uint32_t bit = valid ? 1u << (m * 16 + e) : 0u; // branch-free: a select and an OR per sum (the compiler turned
+                uint32_t bits[3];                                     // `if(…) flagged |= …` into an exec-mask branch per sum)
 #pragma unroll
                 for(int c = 0; c < 3; c++)
                 {
                     const float t = acc[m][c][e] + 16384.0f;
                     bits[c] = __builtin_bit_cast(uint32_t, t);
-                    if(valid && __builtin_fabsf(acc[m][c][e] - (t - 16384.0f)) > inside)
-                        flagged[c] |= 1u << (m * 16 + e);
+                    flagged[c] |= __builtin_fabsf(acc[m][c][e] - (t - 16384.0f)) > inside ? bit : 0u;
                 }
                 const uint32_t rg = __builtin_amdgcn_perm(bits[1], bits[0], 0x0c0c0400u); // [R, G, 0, 0]
                 const uint32_t rgba = __builtin_amdgcn_perm(bits[2], rg, 0x0d040100u);  // [R, G, B, 0xff]
