@@ -76,6 +76,9 @@ __device__ __forceinline__ int store_tile_filtered(const KernelArgs &a, f32x16 (
     const int W = a.width, r = lane & 31, h = lane >> 5;
     int n_st = 0, count = 0; // count: queued entries (wave-uniform)
     uint8_t *plane0 = a.views + ((size_t)vbase * oplane_px + (size_t)y * W + xw) * 4;
+    const uint32_t lane_off = (uint32_t(r) + uint32_t(4 * h) * uint32_t(oplane_px)) * 4u; // < 2^32: four planes of ≤ 2^26 pixels
+    uint64_t stride = (uint64_t)oplane_px * 4;                                            // bytes between the planes of consecutive views
+    asm volatile("" : "+s"(stride));
     auto patch = [&](const int n) { // recompute the first n ≤ 64 queued sums exactly, one per lane
         const uint32_t code = queue[lane < n ? lane : 0];
         const int src = code & 63, e = (code >> 6) & 15, c = (code >> 10) & 3, m = (code >> 12) & 1;
@@ -105,6 +108,7 @@ __device__ __forceinline__ int store_tile_filtered(const KernelArgs &a, f32x16 (
     const float inside = (0.5f - a.std_band) * 0x1p-9f;
     static_assert(MT <= 2, "the per-lane flag words hold 2 × 16 accumulator registers per channel");
     uint32_t flagged[3] = {0u, 0u, 0u}; // per lane and channel: bit m·16 + e ↔ the sum in acc[m][c][e] needs the chain
+    uint32_t valid_mask = 0u;           // bit m·16 + e ↔ this lane stores that sum
 #pragma unroll
     for(int m = 0; m < MT; m++)
     {
@@ -113,32 +117,59 @@ __device__ __forceinline__ int store_tile_filtered(const KernelArgs &a, f32x16 (
         if(nvalid > 0 && xw < W)
         {
             const bool lane_x_ok = xw + r < W;
+            // which of the 16 sums of this m the lane stores: rows (e & 3) + 8·(e >> 2) + 4h below nvalid — a prefix of the e sequence
+            const int lim = max(nvalid - 4 * h, 0);
+            const int n_e = 4 * (lim >> 3) + min(lim & 7, 4);
+            valid_mask |= lane_x_ok ? ((1u << n_e) - 1u) << (16 * m) : 0u;
 #pragma unroll
-            for(int e = 0; e < 16; e++)
+            for(int e0 = 0; e0 < 16; e0 += 2)
             {
-                const int vrow = (e & 3) + 8 * (e >> 2); // + 4h per half-wave
-                if(vrow >= nvalid) // wave-uniform
-                    continue;
-                const bool valid = lane_x_ok && vrow + 4 * h < nvalid;
-                const uint32_t bit = valid ? 1u << (m * 16 + e) : 0u; // branch-free: a select and an OR per sum (the compiler turned
-                uint32_t bits[3];                                     // `if(…) flagged |= …` into an exec-mask branch per sum)
+                // two sums per channel at a time: accumulator registers e0, e0 + 1 are an aligned pair, so t = acc + 2^14 and the
+                // distance d = acc − (t − 2^14) are three v_pk_add_f32 per pair (paired across channels by the compiler they needed moves)
+                float2_t d[3];
+                u32x2 tb[3]; // the bits of t.  NOT `bit_cast<uint32_t>(t[j])`: where only some bits of a float element's bit pattern are used
+                             // (here the low byte) hipcc 7.2 reads element 0 for every element — reproduced in ten lines (`a.y & 0xff` of a
+                             // loaded float2 loads one dword), caught by the one-hot STD test.  Casting the whole vector is compiled correctly.
 #pragma unroll
                 for(int c = 0; c < 3; c++)
                 {
-                    const float t = acc[m][c][e] + 16384.0f;
-                    bits[c] = __builtin_bit_cast(uint32_t, t);
-                    flagged[c] |= __builtin_fabsf(acc[m][c][e] - (t - 16384.0f)) > inside ? bit : 0u;
+                    const float2_t a2 = {acc[m][c][e0], acc[m][c][e0 + 1]};
+                    const float2_t t = a2 + 16384.0f;
+                    d[c] = a2 - (t - 16384.0f);
+                    tb[c] = __builtin_bit_cast(u32x2, t);
                 }
-                const uint32_t rg = __builtin_amdgcn_perm(bits[1], bits[0], 0x0c0c0400u); // [R, G, 0, 0]
-                const uint32_t rgba = __builtin_amdgcn_perm(bits[2], rg, 0x0d040100u);  // [R, G, B, 0xff]
-                uint32_t *out = reinterpret_cast<uint32_t *>(plane0 + ((size_t)(m * 32 + vrow + 4 * h) * oplane_px + r) * 4);
-                n_st++;
-                if(valid)
+#pragma unroll
+                for(int j = 0; j < 2; j++)
                 {
-                    if constexpr(NT_STORE)
-                        __builtin_nontemporal_store(rgba, out);
-                    else
-                        *out = rgba;
+                    const int e = e0 + j;
+                    const int vrow = (e & 3) + 8 * (e >> 2); // + 4h per half-wave
+                    if(vrow >= nvalid) // wave-uniform
+                        continue;
+                    const bool valid = lane_x_ok && vrow + 4 * h < nvalid;
+                    uint32_t bits[3];
+#pragma unroll
+                    for(int c = 0; c < 3; c++)
+                    {
+                        bits[c] = tb[c][j];
+                        // branch-free: a select between two constants and an OR per sum, the lane's validity applied once at the end
+                        // (written as `if(valid && …) flagged |= …` the compiler emitted an exec-mask branch per sum)
+                        flagged[c] |= __builtin_fabsf(d[c][j]) > inside ? 1u << (m * 16 + e) : 0u;
+                    }
+                    const uint32_t rg = __builtin_amdgcn_perm(bits[1], bits[0], 0x0c0c0400u); // [R, G, 0, 0]
+                    const uint32_t rgba = __builtin_amdgcn_perm(bits[2], rg, 0x0d040100u);  // [R, G, B, 0xff]
+                    // Address = a wave-uniform 64-bit row base in SGPRs (scalar arithmetic) + ONE 32-bit per-lane offset, the store written
+                    // with its scalar-base form.  The epilogue is VALU-bound; left to the compiler every store cost a 64-bit vector add, and
+                    // the 32 row offsets — invariant over the kernel — were hoisted: as per-lane values 64 VGPRs, as scalars spilled to VGPR
+                    // lanes (two v_readlane per store).  `stride` is opaque per tile so that they are recomputed by the scalar unit instead.
+                    const uint8_t *row = plane0 + (uint64_t)(m * 32 + vrow) * stride;
+                    n_st++;
+                    if(valid)
+                    {
+                        if constexpr(NT_STORE)
+                            asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(lane_off), "v"(rgba), "s"(row) : "memory");
+                        else
+                            asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_off), "v"(rgba), "s"(row) : "memory");
+                    }
                 }
             }
         }
@@ -148,6 +179,9 @@ __device__ __forceinline__ int store_tile_filtered(const KernelArgs &a, f32x16 (
             for(int e = 0; e < 16; e++)
                 acc[m][c][e] = 0.0f;
     }
+#pragma unroll
+    for(int c = 0; c < 3; c++)
+        flagged[c] &= valid_mask;
     // compact the flagged sums of the wave into the queue, one per lane and round, and recompute them 64 at a time
     while(true)
     {
