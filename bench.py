@@ -271,8 +271,12 @@ def main() -> int:
     device_index = 0 if rehearse else local_rank
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
-    if world > 1:
+    # LFI_BENCH_FORCE_DIST=1: run the process group, the collectives and the barriers with ONE rank too — the only way to execute the
+    # RCCL code path (init with device_id, broadcast / all-gather of the planes, MAX all-reduce) on a one-GPU box
+    collectives = world > 1 or os.environ.get("LFI_BENCH_FORCE_DIST") == "1"
+    if collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -313,7 +317,7 @@ def main() -> int:
             ctx.fill_synthetic(SEED, g0, g1)             # this rank's slice only (real data: this rank's share of the uploads)
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if collectives:
             dist.barrier()
             t_d = time.perf_counter()
             if args.distribute == "broadcast":
@@ -357,7 +361,7 @@ def main() -> int:
     mem = ctx.memory_info()
 
     def barrier():
-        if world > 1:
+        if collectives:
             dist.barrier()
 
     t_pre = time.perf_counter()
@@ -381,7 +385,7 @@ def main() -> int:
     kernel_name = ctx.last_kernel_name()
 
     t = torch.tensor([elapsed, kernel_ms / 1e3], dtype=torch.float64, device=dev)
-    if world > 1:
+    if collectives:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max, kernel_s_max = float(t[0]), float(t[1])
 
@@ -469,7 +473,7 @@ def main() -> int:
             except Exception as e:      # the headline line must come out whatever happens to the extra configurations
                 line["also"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if collectives:
         dist.destroy_process_group()
     return 0
 

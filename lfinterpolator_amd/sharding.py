@@ -27,10 +27,16 @@ def rank_params(cols: int, rows: int, width: int, height: int, trajectory: str, 
     return hp_all.rows(v0, v1), v0, v1
 
 
+def _forced() -> bool:
+    """LFI_BENCH_FORCE_DIST=1: issue the collectives with one rank too (a one-GPU rehearsal of the RCCL calls, bench.py)"""
+    import os
+    return os.environ.get("LFI_BENCH_FORCE_DIST") == "1"
+
+
 def broadcast_grid(grid_tensor, src: int = 0):
     """The job's single collective: rank `src` holds the light field, everybody else receives it (no-op for world 1)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _forced()):
         dist.broadcast(grid_tensor, src=src)
     return grid_tensor
 
@@ -48,7 +54,7 @@ def allgather_grid(flat_tensor, rank: int, world: int):
     gives every rank everything.  Each rank sends 1/G of the bytes instead of rank 0 sending all of them: with xGMI's
     point-to-point links every link carries 1/G of the grid, where a broadcast is bound by the root's links.  No-op for world 1."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _forced()):
         assert flat_tensor.numel() % world == 0
         share = flat_tensor.numel() // world
         dist.all_gather_into_tensor(flat_tensor, flat_tensor[rank * share:(rank + 1) * share].clone())
