@@ -549,10 +549,11 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
         const char *e = std::getenv("LFI_P3_ABLATE");
         return e ? std::atoi(e) : 0;
     }();
-    if(ablate >= 1 && ablate <= 3 && (nch == 1 || nch == 4) && a_in.v1 - a_in.v0 <= 64)
+    if(ablate >= 1 && ablate <= 3 && (nch == 1 || (nch == 4 && a_in.v1 - a_in.v0 <= 64)))
     {
         note_kernel(c, "blend_p3<ABLATION>");
-#define LFI_P3_ABL(N, A) hipLaunchKernelGGL((lfi::blend_p3<true, N, A, (N == 1 ? 1 : 2)>), grid, dim3(N == 1 ? 256 : 128), 0, stream_of(c), a_in, tiles_x, n_tiles, 1, 0)
+        const int abl_passes = nch == 1 ? (a_in.v1 - a_in.v0 + 63) / 64 : 1;
+#define LFI_P3_ABL(N, A) hipLaunchKernelGGL((lfi::blend_p3<true, N, A, (N == 1 ? 1 : 2)>), grid, dim3(N == 1 ? 256 : 128), 0, stream_of(c), a_in, tiles_x, n_tiles, abl_passes, 0)
         if(nch == 1)
         {
             if(ablate == 1) LFI_P3_ABL(1, 1); else if(ablate == 2) LFI_P3_ABL(1, 2); else LFI_P3_ABL(1, 3);
