@@ -22,7 +22,9 @@
 //
 // Pipeline: persistent workgroups, a ring of three pixel buffers in LDS filled by LDS-DMA two units ahead (unit = tile × chunk of
 // 64 images), one barrier and one hand-counted s_waitcnt vmcnt per unit, as in blend_planar's one-chunk path — generalised to
-// any number of chunks (NCH ≤ 4, compile time: the weight fragments of all chunks stay in registers, ≤ 32 VGPRs).
+// any number of chunks (NCH ≤ 4, compile time: the weight fragments of all chunks stay in registers, and the unit loop is unrolled
+// over the chunks of a tile so that they are registers named at compile time).  Launches of several chunks run TWO waves of 32 views
+// per workgroup instead of four of 16 (template parameter VG below): the pixel operand is then built once for two MFMAs.
 // LDS image of a buffer: [channel][octet of images][8 images × 128 B], octets padded so that the four octets a ds_read_b64
 // instruction touches (lanes kg = 0..3) fall into different banks.
 // Arithmetic and quantisation are blend_planar's (weights ×2^15, RN-even to fp16, saturate, truncate — src/kernels.cu:387-396):
