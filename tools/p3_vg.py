@@ -8,6 +8,8 @@ CFG = {2: (8, 8, 1920, 1080, 64, "0,0,1,1", 0.23, 1.783, 3.0), 3: (15, 15, 1920,
 if len(sys.argv) > 1:
     import numpy as np
     import lfinterpolator_amd as L
+    sys.path.insert(0, "tools")
+    import _ablib  # LFI_AB_LIB
     for cfg in (2, 3, 4, "4w", 5):
         cols, rows, W, H, V, traj, focus, aspect, effect = CFG[cfg]
         ctx = L.Context(0)

@@ -4,10 +4,8 @@ import os
 import sys
 sys.path.insert(0, ".")
 import lfinterpolator_amd as L
-if os.environ.get("LFI_AB_LIB"):  # A/B runs of differently built libraries (measurement only)
-    import lfinterpolator_amd.abi as _abi
-    _abi.HIP_LIB = os.path.abspath(os.environ["LFI_AB_LIB"])
-    print("library:", _abi.HIP_LIB)
+sys.path.insert(0, "tools")
+import _ablib  # LFI_AB_LIB: A/B runs of differently built libraries (measurement only)
 cols = rows = 8; W, H, V = 1920, 1080, 64
 ctx = L.Context(0)
 ctx.set_grid(cols, rows, W, H); ctx.fill_synthetic(0x1F1F)
