@@ -136,11 +136,12 @@ def test_planar_layout_weights_outside_unit_range_fall_back(gpu, oracle_c):
     ctx.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_planar_layout_row_bands(world, gpu, oracle_c):
-    """Row-band sharding in the planar layout: every band renders its rows of every view from the input rows it holds."""
-    cols = rows = 8
-    W, H, V = 200, 96, 64
+@pytest.mark.parametrize("world,cols", [(2, 8), (3, 8), (2, 15), (3, 11)])
+def test_planar_layout_row_bands(world, cols, gpu, oracle_c):
+    """Row-band sharding in the planar layout: every band renders its rows of every view from the input rows it holds — with one chunk
+    of images (four waves of 16 views per workgroup) and with several (two waves of 32 views)."""
+    rows = cols
+    W, H, V = 200, 96, 64 if cols == 8 else 40
     hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.1, 0.0, 3.0, 1.783, V)
     full = _ctx(gpu, cols, rows, W, H, hp, layout="rgba")
     full.render("TEN_WM")
