@@ -1,0 +1,21 @@
+# SQ counters of the exact-fp32 STD kernel (blend_persist<STD>) at config 5 fixed focus, RGBA layout: how busy is the matrix pipe?
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+i=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_std15/p$i -o p -- python3 tools/run_p3.py 5 rgba 3 STD > gpurun_out/pmc_std15_$i.log 2>&1 || echo "pass $i failed"
+done
+python3 - <<'PY'
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmc_std15/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][-48:]
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[k]["duration_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+for k in agg:
+    if "blend" in k:
+        print(k)
+        for c, v in sorted(agg[k].items()):
+            print("   %-28s %16.0f" % (c, sum(v) / len(v)))
+PY
