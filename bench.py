@@ -80,15 +80,21 @@ def b_alg(W, rows_in, n_images, rows_out, views):
     return 4.0 * W * (rows_in * n_images + rows_out * views)
 
 
-def timed(ctx, fn, iters: int, warm: int = 3) -> float:
-    """ms per call of fn(): HIP events on the context's launch stream around `iters` back-to-back calls."""
-    for _ in range(warm):
+def timed(ctx, fn, iters: int, warm: int = 3, rounds: int = 3, warm_ms: float = 25.0) -> float:
+    """ms per call of fn(): HIP events on the context's launch stream around `iters` back-to-back calls — the median of `rounds` such
+    measurements, after at least `warm` calls and `warm_ms` of work (a section that starts on an idle GPU otherwise times its clock ramp)."""
+    t0, n = time.perf_counter(), 0
+    while n < warm or (time.perf_counter() - t0) * 1e3 < warm_ms:
         fn()
-    ctx.sync()
-    ctx.timer_start()
-    for _ in range(iters):
-        fn()
-    return ctx.timer_stop() / iters
+        n += 1
+        ctx.sync()
+    res = []
+    for _ in range(rounds):
+        ctx.timer_start()
+        for _ in range(iters):
+            fn()
+        res.append(ctx.timer_stop() / iters)
+    return sorted(res)[len(res) // 2]
 
 
 def also_table(L, device_index: int, iters: int, layout: str) -> dict:
@@ -244,9 +250,10 @@ def main() -> int:
     ap.add_argument("--shard", default="views", choices=["views", "rows"],
                     help="views (default): every GPU holds the whole grid and renders its views; rows: strong scaling of ONE render — each "
                          "GPU renders a band of rows and holds only the input rows the band's warp reaches (SURVEY.md §8(f).2)")
-    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+    ap.add_argument("--prewarm-ms", type=float, default=500.0,
                     help="untimed launches during set-up, before the W warm-up steps, so that the clocks have ramped "
-                         "(with 5 warm-up launches = 1 ms of work the first timed launches still run at idle clocks)")
+                         "(with 5 warm-up launches = 1 ms of work the first timed launches still run at idle clocks; the first process "
+                         "on a fresh box measured 0.167 ms per step after 150 ms of them and 0.150 ms after 600 ms)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
