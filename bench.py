@@ -12,15 +12,18 @@ One "step" = one launch of the blend kernel over the synthetic grid resident in 
 input grid is generated on rank 0 and broadcast ONCE over RCCL/xGMI before the timed region.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
-  roofline     — HBM roofline of the blend kernel: algorithmic bytes 4·W·H·(N_images + V) per launch ÷ the kernel's
-                 average launch time measured with HIP events on the launch stream (through the C-ABI timer); `frac` is on
-                 those algorithmic bytes (SURVEY.md §8(d)), `frac_moved` on the bytes the layouts in use actually need;
+  roofline     — HBM roofline of the blend kernel: the bytes the kernel has to move in the layouts in use (3 B per pixel on an
+                 alpha-free side, 4 B on an RGBA side) ÷ the kernel's average launch time measured with HIP events on the launch
+                 stream (through the C-ABI timer) = `achieved`, `frac`; `frac_algorithmic` is the same on SURVEY.md §8(d)'s
+                 4·W·H·(N_images + V) bytes, which count an alpha byte the planar layouts never touch (comparison only);
   cpu_baseline — the CPU oracle (a port of the reference's STD arithmetic) timed on the host cores on the same
                  workload (N = 1 only).  oracle/ is used here ONLY as that baseline, never in the GPU path;
-  also         — (N = 1) the other BASELINE configurations and methods, timed in the same run after the headline step:
-                 config 3 (15×15 @1080p, 45 views), config 4 per rank and whole, config 5 fixed focus and end to end
-                 (focus map + all-focus render), STD and the non-tensor wavefront kernel at config 2 — each with ms,
-                 algorithmic bytes, roofline fraction and the kernel that ran.
+  cpu_baseline_1thread — the same scalar code on one thread, four full-frame views (SURVEY.md §8(d) (a));
+  also_detail  — (N = 1) the other BASELINE configurations and methods, timed in the same run after the headline step:
+                 config 3 (15×15 @1080p, 45 views; TEN_WM and STD), config 4 per rank and whole, config 5 fixed focus (TEN_WM, STD,
+                 the non-tensor wavefront kernel) and end to end (focus map + all-focus render), cold one-shot renders of configs 2
+                 and 5 — each with ms, algorithmic bytes, roofline fraction and the kernel that ran;
+  also         — the same table, compact ([ms, fraction, kernel] per key), LAST on the line.
 
 Other modes:  --config 4  strong-scaled BASELINE config 4 (8×8 @4K, one 256-view trajectory split over the GPUs);
               --distribute allgather  every rank generates 1/G of the images, one all-gather instead of the broadcast;
@@ -52,26 +55,27 @@ CONFIGS = {
 }
 
 
-def cpu_baseline(cfg, hp, threads: int) -> dict:
-    """The oracle's scalar STD blend on one full step of the same workload, on `threads` host cores."""
+def cpu_baseline(cfg, hp, threads: int, sample_views: int | None = None, budget_s: float = 12.0) -> dict:
+    """The oracle's scalar STD blend on the same workload, on `threads` host cores: whole steps (all views), or — `sample_views` — the
+    first few full-frame views of the step (the single-threaded leg renders min(V, 4) views)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle import lfi_oracle_c as oc
     oc.build()
     n, W, H = cfg["cols"] * cfg["rows"], cfg["W"], cfg["H"]
     lf = np.empty((n, H, W, 4), dtype=np.uint8)
-    with ThreadPoolExecutor(max_workers=threads) as ex:
+    with ThreadPoolExecutor(max_workers=max(threads, 8)) as ex:
         list(ex.map(lambda g: lf.__setitem__(g, oc.synthetic_plane(g, W, H, SEED)), range(n)))
-    # a bounded sample of the same workload: whole steps until ≈ 12 s of CPU work (threads × wall) have been spent, at most 8 steps
+    v = hp.weights.shape[0] if sample_views is None else min(sample_views, hp.weights.shape[0])
+    # a bounded sample of the same workload: passes until ≈ budget_s of CPU work (threads × wall) have been spent, at most 8
     steps, t0 = 0, time.perf_counter()
-    while steps < 8 and (steps == 0 or (time.perf_counter() - t0) * threads < 12.0):
-        oc.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, threads=threads)
+    while steps < 8 and (steps == 0 or (time.perf_counter() - t0) * threads < budget_s):
+        oc.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, v0=0, v1=v, threads=threads)
         steps += 1
     dt = (time.perf_counter() - t0) / steps
-    v = hp.weights.shape[0]
     return {"value": v / dt, "unit": "views/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} step(s): {v} views of {W}x{H} from {n} images each, scalar fp32 FMA weighted mean "
-                      f"(oracle STD), {dt:.2f} s wall per step, {dt * steps * threads:.0f} s of CPU work",
+            "sample": f"{steps} pass(es): {v} views of {W}x{H} from {n} images each, scalar fp32 FMA weighted mean "
+                      f"(oracle STD), {dt:.2f} s wall per pass, {dt * steps * threads:.0f} s of CPU work",
             "gpix_per_s": v * W * H / dt / 1e9}
 
 
@@ -166,6 +170,9 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
             ctx.set_output_layout(layout)
         ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters)
         out["config3"] = entry(c3, ms, 45, ctx.last_kernel_name())
+        ctx.set_output_layout("rgba")
+        ms = timed(ctx, lambda: ctx.render("STD"), max(2, iters // 2))
+        out["config3_std"] = entry(c3, ms, 45, ctx.last_kernel_name(), "bit-exact STD on a 15x15 grid (four chunks of images)", flops_bound=True)
         ctx.close()
 
     guarded(config3)
@@ -201,6 +208,14 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         ms = timed(ctx, lambda: ctx.render("TEN_WM"), max(2, iters // 2))
         out["config5_fixed_focus"] = entry(c5, ms, 64, ctx.last_kernel_name())
         ctx.set_output_layout("rgba")
+        # BASELINE config 5's comparison, fixed focus: bit-exact STD by the default kernel and by the NON-TENSOR wavefront kernel
+        # (blend_std_vfma, the analogue of Standard::process, src/kernels.cu:312-342)
+        ms = timed(ctx, lambda: ctx.render("STD"), max(2, iters // 4), warm=1)
+        out["config5_fixed_focus_std"] = entry(c5, ms, 64, ctx.last_kernel_name(), "bit-exact STD, default kernel", flops_bound=True)
+        ctx.set_variant("STD", "vfma")
+        ms = timed(ctx, lambda: ctx.render("STD"), 2, warm=1, rounds=2)
+        out["config5_fixed_focus_std_nontensor"] = entry(c5, ms, 64, ctx.last_kernel_name(), "the non-tensor wavefront kernel (v_pk_fma_f32 chains)", flops_bound=True)
+        ctx.set_variant("STD", "auto")
         # the focus sweep on a STRUCTURED light field: a texture seen at a piecewise-constant focus inside
         # [focus, focus + range], so that the estimated map is piecewise constant as on real scenes — on hash noise the map is noise and
         # the all-focus gathers touch one cache line per pixel (measured: 17 ms instead of ≈2 ms), which no real input does
@@ -220,9 +235,41 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
             out[key + "_render"] = entry(c5, ms_r, 64, k, "all-focus render from a resident focus map (structured light field)", flops_bound=(method == "STD"))
             out[key + "_end_to_end"] = entry(c5, ms_e, 64, "focus map + " + k, "lfi_focus_map + all-focus render per iteration (-r 0.17)",
                                              in_bytes_extra=map_in + map_io, flops_bound=(method == "STD"))
+        ctx.set_variant("STD", "vfma")
+        ms_r = timed(ctx, lambda: ctx.render("STD", all_focus=True), 2, warm=1, rounds=2)
+        out["config5_allfocus_std_nontensor"] = entry(c5, ms_r, 64, ctx.last_kernel_name(), "all-focus render by the non-tensor wavefront kernel", flops_bound=True)
         ctx.close()
 
     guarded(config5)
+
+    # ---- cold, one-shot: inputs resident in HBM, caches flushed → everything the library derives from them + the FIRST render ------
+    # (the reference's actual flow minus its 100-launch benchmark loop, src/interpolator.cu:248-297; every other number on this line is a
+    # steady-state launch with the derived input copy in place and the sweep direction alternating)
+    def cold_one_shot():
+        import torch
+        flush = torch.empty(768 << 20, dtype=torch.uint8, device=f"cuda:{device_index}")   # 3× the Infinity Cache
+        for key, cfg in (("config2", CONFIGS[2]), ("config5", CONFIGS[5])):
+            res = []
+            for rep in range(3):
+                ctx, hp = make_ctx(cfg, rng=0.0)
+                ctx.set_params(hp, flags=L.LFI_FLAG_SINGLE_SWEEP_DIRECTION)
+                if layout != "rgba":
+                    ctx.set_output_layout(layout)
+                ctx.sync()
+                flush.fill_(rep)
+                torch.cuda.synchronize()
+                ctx.timer_start()
+                ctx.render("TEN_WM")
+                res.append(ctx.timer_stop())
+                k = ctx.last_kernel_name()
+                mem = ctx.memory_info()
+                ctx.close()
+            out[key + "_cold_one_shot"] = entry(cfg, sorted(res)[1], cfg["views"], k,
+                                                f"a fresh context's first render, caches flushed, one sweep direction: includes whatever the "
+                                                f"library derives from the inputs first ({mem.derived_bytes / 1e6:.0f} MB derived copy); median of 3")
+        del flush
+
+    guarded(cold_one_shot)
 
     return out
 
@@ -447,19 +494,25 @@ def main() -> int:
                                        f"rows sharded over {world} GPU(s): {out_rows_n} output rows from {in_rows_n} input rows on rank 0, "
                                        "no collective"),
                        "distribute_ms": distribute_ms,
+                       "view_ranges": ([list(L.view_range(total_views, world, r)) for r in range(world)] if args.shard == "views" else None),
+                       "row_bands": ([list(L.row_band(HEIGHT, world, r)) for r in range(world)] if args.shard == "rows" else None),
                        "multi_gpu_hardware_runs": ("this line" if world > 1 and not rehearse else
                                                    "none by the builder: gpurun offers one GPU; N > 1 is covered by gloo tests and a one-GPU "
                                                    "rehearsal, the driver's SCALE run is the first RCCL execution")},
             "gpix_per_s": value * WIDTH * HEIGHT / 1e9,
             "prewarm_ms": args.prewarm_ms,
             "kernel_ms_per_launch": t_launch * 1e3,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            # `achieved` / `frac`: the bytes the kernel has to MOVE in the layouts in use (3 B per pixel on a side that is alpha-free,
+            # 4 B on an RGBA side) ÷ the launch time — what the memory system delivered.  SURVEY.md §8(d)'s algorithmic figure
+            # 4·W·H·(N + V) counts an alpha byte on both sides that the planar layouts never touch; a fraction on it (`frac_algorithmic`)
+            # credits the kernel with bytes it did not move (round 2's 0.88 was that figure) and is kept for comparison only.
+            "roofline": {"bound": "hbm", "achieved": b_moved / t_launch / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": b_moved / t_launch / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiled constant: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/traffic.json "
                                            "(not measured in this run)" if traffic else None,
-                         "algorithmic_bytes_per_launch": balg,
-                         "layout_bytes_per_launch": b_moved, "frac_moved": b_moved / t_launch / 1e9 / HBM_PEAK_GBS,
-                         "frac_of_measured_copy_6290": achieved / 6290.0,
+                         "bytes_per_launch": b_moved,
+                         "bytes_definition": f"layout bytes: {3 if reads_planar else 4} B per pixel and image read, {out_bpp} B per pixel and view written",
+                         "algorithmic_bytes_per_launch": balg, "achieved_algorithmic": achieved, "frac_algorithmic": achieved / HBM_PEAK_GBS,
                          "mfma_frac_of_2500_tflops": f_alg / t_launch / 1e12 / F16_MFMA_PEAK_TFLOPS},
         }
         if args.method == "STD" and args.variant not in ("auto", "filtered_m2_nt"):
@@ -472,6 +525,8 @@ def main() -> int:
         if world == 1 and not args.no_cpu_baseline and args.config == 2:
             threads = min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(cfg, hp, threads)
+            # the same scalar code on ONE thread, min(V, 4) full-frame views
+            line["cpu_baseline_1thread"] = cpu_baseline(cfg, hp, 1, sample_views=4, budget_s=8.0)
 
     ctx.close()
     del views, grid
@@ -479,9 +534,28 @@ def main() -> int:
     if rank == 0:
         if world == 1 and not args.no_also and args.config == 2 and args.shard == "views":
             try:
-                line["also"] = also_table(L, device_index, args.also_iters, args.layout)
+                detail = also_table(L, device_index, args.also_iters, args.layout)
             except Exception as e:      # the headline line must come out whatever happens to the extra configurations
-                line["also"] = {"error": f"{type(e).__name__}: {e}"}
+                detail = {"error": f"{type(e).__name__}: {e}"}
+            line["also_detail"] = detail
+            # the headline's two companions (same kernel family, same inputs): one sweep direction only, and the reference's RGBA views
+            for key, name in (("config2_ten_wm_single_sweep_direction", "single_sweep_direction_ms"), ("config2_ten_wm_rgba_views", "rgba_views_ms")):
+                if isinstance(detail.get(key), dict):
+                    line["roofline"][name] = detail[key]["ms"]
+            # LAST on the line, compact, so that a reader who keeps only the tail of the output still has every configuration:
+            # [ms per launch, fraction of the bound (HBM 8 TB/s on 4·W·H·(N+V) bytes, or fp32 157.3 TFLOP/s where the kernel is fp32-bound), kernel]
+            compact = {"legend": "[ms, frac of 8 TB/s on 4WH(N+V) bytes | 'fp32:' frac of 157.3 TFLOP/s, kernel]"}
+            for key, e in detail.items():
+                if isinstance(e, dict) and "ms" in e:
+                    fr = f"fp32:{e['fp32_frac']:.3f}" if e.get("bound") == "fp32" else round(e.get("frac", 0.0), 3)
+                    compact[key] = [round(e["ms"], 4), fr, e.get("kernel", "")]
+                else:
+                    compact[key] = e
+            if "cpu_baseline_1thread" in line:
+                compact["cpu_baseline_1thread_views_per_s"] = round(line["cpu_baseline_1thread"]["value"], 2)
+            if "cpu_baseline" in line:
+                compact["cpu_baseline_views_per_s"] = [round(line["cpu_baseline"]["value"], 1), line["cpu_baseline"]["cores"]]
+            line["also"] = compact
         print(json.dumps(line), flush=True)
     if collectives:
         dist.destroy_process_group()

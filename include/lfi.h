@@ -62,7 +62,13 @@ enum {
      * one launch read last — still in the 256 MB Infinity Cache — are the first the next launch reads (repeated renders of one light
      * field: the reference's 100-launch loop, trajectory blocks, focus sweeps).  With this flag every launch walks the image in
      * ascending order, as a single cold launch does.  Results are identical either way. */
-    LFI_FLAG_SINGLE_SWEEP_DIRECTION = 4u
+    LFI_FLAG_SINGLE_SWEEP_DIRECTION = 4u,
+    /* STD through the band method (fp16 matrix-core sum, exact fmaf chain only for sums near x.5): size the band with the ANALYTIC
+     * bound on the matrix core's accumulation error (one whole fp16-product ulp per addend, true of any accumulator that keeps ≥ 24
+     * bits even if every addition truncated) instead of the bound measured on gfx950 (a quarter ulp per addend; asserted by
+     * tests/test_gpu_parity.py::test_mfma_f16_accumulation_error_bound).  Same bytes, ≈ 1.5× as many sums recomputed.  For callers
+     * who do not want bit-exactness to rest on a measured property of the hardware. */
+    LFI_FLAG_STD_ANALYTIC_BAND = 8u
 };
 
 #define LFI_MAX_IMAGES 256     /* MAX_IMAGES, src/kernels.cu:60 */

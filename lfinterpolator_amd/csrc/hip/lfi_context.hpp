@@ -1,0 +1,359 @@
+// lfi_context.hpp — the context behind include/lfi.h's opaque lfi_ctx: device memory, streams and events, the parameter block, and
+// the small helpers every entry point uses (error convention, stream joins, plane sizes, the kernel-argument block).
+// This is the device-facing state of the reference's Interpolator (reference src/interpolator.cu:36-154: surfaces, __constant__ symbols,
+// the weights allocation) as one object per GPU.  Included by lfi_hip.hip only (one translation unit).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/lfi.h"
+#include "lfi_device.hpp"
+#include "quality.hpp"
+
+using lfi::KernelArgs;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+} // namespace
+
+struct lfi_ctx
+{
+    int device = 0;
+    int cu_count = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_order = nullptr; // orders the work of the stream a caller switches away from before the stream it switches to
+    // asynchronous uploads (lfi_upload_image_async) and downloads of lfi_render_stream: a copy stream
+    hipStream_t copy_stream = nullptr;
+    bool uploads_pending = false; // copies enqueued on copy_stream that the compute stream has not been ordered after yet
+    hipEvent_t ev_uploads = nullptr;
+    // side stream of the factored focus-map estimate (its small passes overlap the large ones), created on first use
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_pad = nullptr, ev_join = nullptr;
+    int cols = 0, rows = 0, n = 0, width = 0, height = 0;
+    // row window (lfi_set_row_window): input rows held / output rows rendered; the whole image by default
+    int in_y0 = 0, in_rows = 0, out_y0 = 0, out_rows = 0;
+    bool windowed = false;
+    uint8_t *grid = nullptr;
+    bool own_grid = false;
+    size_t grid_bytes = 0;
+    uint8_t *maps = nullptr;
+    uint8_t *views = nullptr;
+    bool own_views = false;
+    size_t views_bytes = 0;
+    int out_layout = LFI_LAYOUT_RGBA;  // device layout of the views (lfi_set_output_layout)
+    uint8_t *rgba_scratch = nullptr;   // planar layout: RGBA planes of all views for the kernels that only write RGBA (converted after the launch)
+    size_t rgba_scratch_bytes = 0;
+    uint8_t *dl_plane = nullptr;       // planar layout: one RGBA plane that downloads expand a view into
+    size_t dl_plane_bytes = 0;
+    // parameter block
+    bool have_params = false;
+    int views_n = 0, k_pad = 0, v_pad = 0, n_focus_ids = 0;
+    void *param_blob = nullptr; // one allocation holding all parameter arrays
+    size_t blob_off_w16 = 0, blob_weights_bytes = 0; // the four weight arrays inside the blob (what lfi_render_stream replaces per block)
+    // lfi_render_stream: page-locked staging for two blocks' weight arrays, a second set of views, events
+    uint8_t *stream_staging[2] = {nullptr, nullptr};
+    size_t stream_staging_bytes = 0;
+    uint8_t *views2 = nullptr;
+    size_t views2_bytes = 0;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_rendered[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
+    lfi::QualitySums *quality_sums = nullptr; // lfi_compare_view
+    uint8_t *quality_ref = nullptr;
+    size_t quality_ref_bytes = 0;
+    lfi_int2 *d_focused = nullptr;
+    lfi_float2 *d_offsets = nullptr;
+    uint16_t *d_w16 = nullptr, *d_w16s = nullptr;
+    bool weights_scalable = false; // every weight finite and in [0, 2): the ×2^15 copy is exact and the packed epilogue valid
+    bool weights_sum_ok = false;   // … and every view's weights sum to at most 2: blend_planar<STDF>'s error bounds hold (sums < 512)
+    float *d_w32 = nullptr, *d_w32t = nullptr;
+    int32_t *d_ids = nullptr;
+    float focus = 0, range = 0;
+    int radius[2] = {1, 1};
+    int fo_min[2] = {0, 0}, fo_max[2] = {0, 0}; // bounds of the integer offsets
+    uint32_t flags = 0;
+    float *prequant = nullptr;
+    std::vector<lfi_float2> h_focus_offsets; // offsets of the focus_map_ids images (host copy: sizes the padded planes)
+    std::vector<lfi_float2> h_offsets;       // offsets of all images (host copy: row-window coverage checks of all-focus renders)
+    // planar copy of the inputs for blend_planar (built on demand; valid while planar_version == grid_version)
+    uint8_t *planar = nullptr;
+    size_t planar_bytes = 0;
+    int planar_pitch = 0, planar_padx = 0;
+    uint64_t grid_version = 1, planar_version = 0;
+    bool grid_tracked = true; // every write to the planes goes through this library (or is announced by lfi_grid_modified)
+    void *focus_ws = nullptr; // workspace of the factored focus-map estimate (plan, E, K), allocated on first use
+    size_t focus_ws_bytes = 0;
+    int ten_variant = 0, std_variant = 0, focus_variant = 0;
+    mutable const char *last_kernel = ""; // the blend kernel the last render launched (lfi_last_kernel_name)
+    mutable unsigned sweep_launches = 0;  // blend_p3 / blend_planar alternate their sweep direction from launch to launch
+    float derived_build_ms = 0.0f;        // duration of the last planar_build (measured by lfi_prepare only)
+    std::string err;
+};
+
+namespace {
+
+// The context's own views in the planar layout live in UNCACHED device memory: they are write-only for the renders (full 128-byte
+// lines, non-temporal stores), and planes that bypass the caches leave more of the Infinity Cache to the inputs the next launch
+// re-reads (tools/views_mtype.py, config 2: 150 µs against 156 µs per launch).  RGBA views stay in ordinary memory (the STD band
+// epilogue patches single bytes behind its dword stores).  LFI_VIEWS_MEMORY=default|uncached|finegrained overrides (experiments).
+hipError_t alloc_views(uint8_t **out, size_t bytes, bool planar_layout)
+{
+    static const int forced = [] {
+        const char *e = std::getenv("LFI_VIEWS_MEMORY");
+        return !e ? -1 : (std::strcmp(e, "uncached") == 0 ? 1 : (std::strcmp(e, "finegrained") == 0 ? 2 : 0));
+    }();
+    const int kind = forced >= 0 ? forced : (planar_layout ? 1 : 0);
+    if(kind == 1)
+        return hipExtMallocWithFlags(reinterpret_cast<void **>(out), bytes, hipDeviceMallocUncached);
+    if(kind == 2)
+        return hipExtMallocWithFlags(reinterpret_cast<void **>(out), bytes, hipDeviceMallocFinegrained);
+    return hipMalloc(reinterpret_cast<void **>(out), bytes);
+}
+
+int fail(lfi_ctx *ctx, int code, const std::string &msg)
+{
+    if(ctx)
+        ctx->err = msg;
+    else
+        g_create_error = msg;
+    return code;
+}
+
+#define LFI_HIP(ctx, call)                                                                                            \
+    do                                                                                                                \
+    {                                                                                                                 \
+        hipError_t e_ = (call);                                                                                       \
+        if(e_ != hipSuccess)                                                                                          \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? LFI_ENOMEM : LFI_EHIP,                                       \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                                           \
+    } while(0)
+
+int bind(lfi_ctx *ctx)
+{
+    LFI_HIP(ctx, hipSetDevice(ctx->device));
+    return LFI_OK;
+}
+
+// Order everything enqueued on the compute stream from now on after the asynchronous uploads issued so far (no host wait).
+int join_uploads(lfi_ctx *c)
+{
+    if(!c->uploads_pending)
+        return LFI_OK;
+    LFI_HIP(c, hipEventRecord(c->ev_uploads, c->copy_stream));
+    LFI_HIP(c, hipStreamWaitEvent(c->stream, c->ev_uploads, 0));
+    c->uploads_pending = false;
+    return LFI_OK;
+}
+
+int ensure_copy_stream(lfi_ctx *c)
+{
+    if(c->copy_stream)
+        return LFI_OK;
+    LFI_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    LFI_HIP(c, hipEventCreateWithFlags(&c->ev_uploads, hipEventDisableTiming));
+    return LFI_OK;
+}
+
+size_t plane_bytes(const lfi_ctx *c) // a whole-image plane (focus maps; inputs and outputs without a row window)
+{
+    return (size_t)c->width * c->height * 4;
+}
+
+size_t in_plane_bytes(const lfi_ctx *c)
+{
+    return (size_t)c->width * c->in_rows * 4;
+}
+
+// planar view layout: bytes per row of a byte plane — a multiple of 16 so that every 8-byte store of blend_p3 is aligned and stays
+// inside its row whatever the width
+int view_pitch(const lfi_ctx *c)
+{
+    return (c->width + 15) / 16 * 16;
+}
+
+size_t rgba_out_plane_bytes(const lfi_ctx *c)
+{
+    return (size_t)c->width * c->out_rows * 4;
+}
+
+size_t out_plane_bytes(const lfi_ctx *c) // one view as stored on the device
+{
+    if(c->out_layout == LFI_LAYOUT_PLANAR_RGB)
+        return (size_t)3 * c->out_rows * view_pitch(c);
+    return rgba_out_plane_bytes(c);
+}
+
+KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
+{
+    KernelArgs a{};
+    a.grid = c->grid;
+    a.views = c->views;
+    a.maps = c->maps;
+    a.focused = c->d_focused;
+    a.offsets = c->d_offsets;
+    a.w16 = c->d_w16;
+    a.w16s = c->d_w16s;
+    a.w32 = c->d_w32;
+    a.w32t = c->d_w32t;
+    a.focus_ids = c->d_ids;
+    a.prequant = nullptr;
+    a.prequant_view = -1;
+    a.width = c->width;
+    a.height = c->height;
+    a.in_y0 = c->in_y0;
+    a.in_rows = c->in_rows;
+    a.out_y0 = c->out_y0;
+    a.out_rows = c->out_rows;
+    a.map_y0 = 0;
+    a.map_rows = c->height;
+    a.n_images = c->n;
+    a.k_pad = c->k_pad;
+    a.v_pad = c->v_pad;
+    a.v0 = v0;
+    a.v1 = v1;
+    a.n_focus_ids = c->n_focus_ids;
+    a.planar = nullptr; // set by launch_blend when the copy is valid for this launch
+    // blend_planar<STDF>: chain bound N·2^-16 (half an ulp below 512 per fmaf: arithmetic) + MFMA accumulation bound N·2^-17 (a
+    // quarter ulp per addend: MEASURED on gfx950 — chains of v_mfma_f32_32x32x16_f16 on operands built to expose alignment
+    // truncation stay within 0.086 ulp per addend, tests/test_gpu_parity.py::test_mfma_f16_accumulation_error_bound asserts the
+    // quarter ulp used here) + 2^-11 of margin
+    a.std_band = float(c->n) * (0x1p-16f + 0x1p-17f) + 0x1p-11f;
+    if(c->flags & LFI_FLAG_STD_ANALYTIC_BAND) // N·2^-15 for the accumulation: nothing measured (include/lfi.h)
+        a.std_band = float(c->n) * (0x1p-16f + 0x1p-15f) + 0x1p-11f;
+    a.planar_pitch = c->planar_pitch;
+    a.planar_padx = c->planar_padx;
+    a.views_pitch = view_pitch(c);
+    a.fo_min_x = c->fo_min[0];
+    a.fo_max_x = c->fo_max[0];
+    a.fo_min_y = c->fo_min[1];
+    a.fo_max_y = c->fo_max[1];
+    a.radius_x = c->radius[0];
+    a.radius_y = c->radius[1];
+    // the reference reads map 1 in Standard::process and map 0 in Tensors::process (src/kernels.cu:326 vs :430): reproduced by
+    // default; LFI_FLAG_UNIFIED_FOCUS_MAP makes both read the filtered map
+    a.map_index = 1;
+    if(all_focus_method == LFI_METHOD_TEN_WM && !(c->flags & LFI_FLAG_UNIFIED_FOCUS_MAP))
+        a.map_index = 0;
+    a.focus = c->focus;
+    a.range = c->range;
+    a.flags = c->flags;
+    return a;
+}
+
+dim3 pixel_grid(const lfi_ctx *c)
+{
+    return dim3((c->width + 63) / 64, (c->height + 3) / 4, 1);
+}
+
+
+inline hipStream_t stream_of(const lfi_ctx *c) { return c->stream; }
+inline void note_kernel(const lfi_ctx *c, const char *name) { c->last_kernel = name; }
+inline uint32_t flags_of(const lfi_ctx *c) { return c->flags; }
+inline dim3 pixel_grid_of(const lfi_ctx *c) { return pixel_grid(c); }
+inline int cu_count_of(const lfi_ctx *c) { return c->cu_count; }
+
+// The four device forms of a block of `rows` weight rows: fp16 as given, ×2^15 (exact; valid iff every weight is finite and in
+// [0, 2)), f32, and f32 transposed — written at base + 0 / off_w16s / off_w32 / off_w32t (the region must be zero-initialised:
+// padding rows and images stay zero).  *scalable / *sums_ok: the dispatch conditions lfi_set_params records.
+void fill_weight_arrays(const uint16_t *weights_fp16, int rows, int n, int k_pad, int v_pad, uint8_t *base, size_t off_w16s, size_t off_w32, size_t off_w32t,
+                        bool *scalable_out, bool *sums_ok_out)
+{
+    uint16_t *w16 = reinterpret_cast<uint16_t *>(base);
+    uint16_t *w16s = reinterpret_cast<uint16_t *>(base + off_w16s);
+    float *w32 = reinterpret_cast<float *>(base + off_w32);
+    float *w32t = reinterpret_cast<float *>(base + off_w32t);
+    bool scalable = true;
+    for(int v = 0; v < rows; v++)
+        for(int g = 0; g < n; g++)
+        {
+            const uint16_t h = weights_fp16[(size_t)v * n + g];
+            const float f = static_cast<float>(__builtin_bit_cast(_Float16, h)); // half → float is exact
+            w16[(size_t)v * k_pad + g] = h;
+            // × 2^15 is exact in fp16 for every finite weight in [0, 2) (subnormals become normal, 1.999 → 65472)
+            if(!(f >= 0.0f && f < 2.0f))
+                scalable = false;
+            else
+                w16s[(size_t)v * k_pad + g] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(f * 32768.0f));
+            w32[(size_t)v * k_pad + g] = f;
+            w32t[(size_t)g * v_pad + v] = f;
+        }
+    bool sums_ok = scalable;
+    for(int v = 0; v < rows && sums_ok; v++)
+    {
+        double sum = 0;
+        for(int g = 0; g < n; g++)
+            sum += w32[(size_t)v * k_pad + g];
+        sums_ok = sum <= 2.0;
+    }
+    *scalable_out = scalable;
+    *sums_ok_out = sums_ok;
+}
+
+void free_params(lfi_ctx *c)
+{
+    if(c->param_blob)
+        (void)hipFree(c->param_blob);
+    c->param_blob = nullptr;
+    c->have_params = false;
+}
+
+void free_views(lfi_ctx *c)
+{
+    if(c->own_views && c->views)
+        (void)hipFree(c->views);
+    c->views = nullptr;
+    c->own_views = false;
+    c->views_bytes = 0;
+    if(c->rgba_scratch)
+        (void)hipFree(c->rgba_scratch);
+    c->rgba_scratch = nullptr;
+    c->rgba_scratch_bytes = 0;
+    if(c->dl_plane)
+        (void)hipFree(c->dl_plane);
+    c->dl_plane = nullptr;
+    c->dl_plane_bytes = 0;
+    if(c->views2)
+        (void)hipFree(c->views2);
+    c->views2 = nullptr;
+    c->views2_bytes = 0;
+    if(c->quality_ref)
+        (void)hipFree(c->quality_ref);
+    c->quality_ref = nullptr;
+    c->quality_ref_bytes = 0;
+}
+
+void free_grid(lfi_ctx *c)
+{
+    if(c->own_grid && c->grid)
+        (void)hipFree(c->grid);
+    c->grid = nullptr;
+    c->own_grid = false;
+    c->grid_bytes = 0;
+    if(c->maps)
+        (void)hipFree(c->maps);
+    c->maps = nullptr;
+    if(c->prequant)
+        (void)hipFree(c->prequant);
+    c->prequant = nullptr;
+    if(c->focus_ws)
+        (void)hipFree(c->focus_ws);
+    c->focus_ws = nullptr;
+    c->focus_ws_bytes = 0;
+    if(c->planar)
+        (void)hipFree(c->planar);
+    c->planar = nullptr;
+    c->planar_bytes = 0;
+    c->planar_version = 0;
+}
+
+} // namespace

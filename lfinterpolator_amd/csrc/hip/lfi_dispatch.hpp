@@ -1,0 +1,489 @@
+// lfi_dispatch.hpp — which kernel serves a render: the variant tables (lfi_set_variant), the launchers of every blend kernel, the
+// derived planar input copy (ensure_planar) and the rules that pick between them (wants_planar, wants_p3, launch_blend).
+// Replaces the method / allFocus dispatch of Interpolator::interpolate (reference src/interpolator.cu:270-290).
+// Included by lfi_hip.hip only (one translation unit), after lfi_context.hpp.
+#pragma once
+
+#include "lfi_context.hpp"
+#include "blend_std.hpp"
+#include "blend_ten.hpp"
+#include "blend_ten_persist.hpp"
+#include "blend_planar.hpp"
+#include "blend_p3.hpp"
+#include "blend_wave.hpp"
+
+namespace {
+
+struct Variant
+{
+    const char *name;
+    void (*launch)(const lfi_ctx *, const KernelArgs &, bool all_focus);
+    bool packed_epilogue; // TEN_WM: needs weights in [0,2) (×2^15 copy)
+    bool prequant = false; // can dump pre-quantisation accumulators (the generic kernels only)
+    bool row_window = false; // honours a row window (the persistent kernels)
+    bool planar = false;     // reads the planar copy of the inputs when the launch qualifies (else its launcher falls back)
+};
+
+int next_sweep_direction(const lfi_ctx *c);
+
+template <int PXL, int MT>
+void launch_ten_direct(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    const int tiles_x = (a.width + 32 * PXL - 1) / (32 * PXL);
+    const int n_tiles = tiles_x * a.height;
+    const int passes = (a.v1 - a.v0 + 32 * MT - 1) / (32 * MT);
+    const int vpw = passes >= 4 ? 4 : (passes >= 2 ? 2 : 1);
+    const int tiles_per_wg = 4 / vpw;
+    const dim3 grid((n_tiles + tiles_per_wg - 1) / tiles_per_wg), block(256);
+    hipStream_t st = stream_of(c);
+    note_kernel(c, "blend_ten_direct");
+    if constexpr(PXL == 1 && MT == 2)
+    {
+        if(flags_of(c) & LFI_FLAG_TEN_ROUND_PER_BATCH)
+        {
+            if(all_focus)
+                hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, true, true>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
+            else
+                hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false, true>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
+            return;
+        }
+    }
+    if(all_focus)
+        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, true, false>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
+    else
+        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false, false>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
+}
+
+template <bool STD, int MT, bool NT_STORE, int KC = 64, int WGS = 2>
+void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    constexpr int TPX = 128, VPP = MT * 32;
+    const int tiles_x = (a.width + TPX - 1) / TPX;
+    const int n_tiles = tiles_x * a.out_rows;
+    const int passes = (a.v1 - a.v0 + VPP - 1) / VPP;
+    // persistent: WGS workgroups per CU (2 x 80 KB of LDS at KC = 64), each walks tiles j, j+G, j+2G ...
+    const dim3 grid(std::min(n_tiles, WGS * cu_count_of(c))), block(256);
+    note_kernel(c, STD ? (all_focus ? "blend_persist<STD,allfocus>" : "blend_persist<STD>") : (all_focus ? "blend_persist<TEN_WM,allfocus>" : "blend_persist<TEN_WM>"));
+    if(all_focus)
+        hipLaunchKernelGGL((lfi::blend_persist<STD, MT, true, NT_STORE, KC, WGS>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
+    else
+        hipLaunchKernelGGL((lfi::blend_persist<STD, MT, false, NT_STORE, KC, WGS>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
+}
+
+// TEN_WM from the planar copy of the inputs (blend_planar.hpp) when launch_blend has validated it for this launch
+// (a.planar != nullptr: fixed focus), else blend_persist
+template <bool NT_STORE, int RING3 = 1>
+void launch_planar(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    if(!a.planar || all_focus)
+    {
+        launch_persist<false, 2, NT_STORE>(c, a, all_focus);
+        return;
+    }
+    const int tiles_x = (a.width + 127) / 128;
+    const int n_tiles = tiles_x * a.out_rows;
+    const int passes = (a.v1 - a.v0 + 63) / 64;
+    const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    note_kernel(c, "blend_planar<TEN_WM>");
+    hipLaunchKernelGGL((lfi::blend_planar<2, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, RING3, next_sweep_direction(c));
+}
+
+// wave-private pipelines (blend_wave.hpp) where they apply — fixed focus, one K-chunk, one view pass — else blend_persist
+template <bool STD, int MT, bool NT_STORE>
+void launch_wave(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    if(all_focus || a.k_pad > 64 || a.v1 - a.v0 > 32 * MT)
+    {
+        launch_persist<STD, MT, NT_STORE>(c, a, all_focus);
+        return;
+    }
+    const int tiles_x = (a.width + 127) / 128;
+    const int n_tiles = tiles_x * a.out_rows;
+    const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    note_kernel(c, STD ? "blend_wave<STD>" : "blend_wave<TEN_WM>");
+    hipLaunchKernelGGL((lfi::blend_wave<STD, MT, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles);
+}
+
+// STD through blend_planar<STDF> (MFMA sum + exact recomputation inside the rounding band) when launch_blend has validated the
+// planar copy and the weights for it, else the exact-fp32 MFMA kernels
+void launch_std_filtered(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    if(!a.planar || all_focus || a.k_pad > 64)
+    {
+        launch_wave<true, 2, true>(c, a, all_focus);
+        return;
+    }
+    const int tiles_x = (a.width + 127) / 128;
+    const int n_tiles = tiles_x * a.out_rows;
+    const int passes = (a.v1 - a.v0 + 63) / 64;
+    const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    note_kernel(c, "blend_planar<STDF>");
+    hipLaunchKernelGGL((lfi::blend_planar<2, true, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, 0, next_sweep_direction(c));
+}
+
+template <int PXL, int MT>
+void launch_std_mfma(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    const int tiles_x = (a.width + 32 * PXL - 1) / (32 * PXL);
+    const int n_tiles = tiles_x * a.height;
+    const int passes = (a.v1 - a.v0 + 32 * MT - 1) / (32 * MT);
+    const int vpw = passes >= 4 ? 4 : (passes >= 2 ? 2 : 1);
+    const int tiles_per_wg = 4 / vpw;
+    const dim3 grid((n_tiles + tiles_per_wg - 1) / tiles_per_wg), block(256);
+    note_kernel(c, "blend_std_mfma");
+    if(all_focus)
+        hipLaunchKernelGGL((lfi::blend_std_mfma<PXL, MT, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, vpw);
+    else
+        hipLaunchKernelGGL((lfi::blend_std_mfma<PXL, MT, false>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, vpw);
+}
+
+void launch_std_valu(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    note_kernel(c, "blend_std_valu");
+    if(all_focus)
+        hipLaunchKernelGGL((lfi::blend_std_valu<true, 16>), pixel_grid_of(c), dim3(256), 0, stream_of(c), a);
+    else
+        hipLaunchKernelGGL((lfi::blend_std_valu<false, 16>), pixel_grid_of(c), dim3(256), 0, stream_of(c), a);
+}
+
+void launch_std_vfma(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    note_kernel(c, "blend_std_vfma");
+    if(all_focus)
+        hipLaunchKernelGGL((lfi::blend_std_vfma<true>), pixel_grid_of(c), dim3(256), 0, stream_of(c), a);
+    else
+        hipLaunchKernelGGL((lfi::blend_std_vfma<false>), pixel_grid_of(c), dim3(256), 0, stream_of(c), a);
+}
+
+// first entry = default ("auto")
+const Variant kTenVariants[] = {
+    {"planar_m2_nt", launch_planar<true>, true, false, true, true}, // blend_persist where blend_planar does not apply
+    {"persist_m2_nt", launch_persist<false, 2, true>, true, false, true},
+    {"wave_m2_nt", launch_wave<false, 2, true>, true, false, true},
+    {"direct_p1m2", launch_ten_direct<1, 2>, false, true}, // generic: any weights, pre-quantisation dump, per-batch rounding
+};
+const Variant kStdVariants[] = {
+    {"filtered_m2_nt", launch_std_filtered, false, false, true, true}, // blend_wave / blend_persist where it does not apply
+    {"wave_m2_nt", launch_wave<true, 2, true>, false, false, true},    // blend_persist where blend_wave does not apply
+    {"persist_m2_nt", launch_persist<true, 2, true>, false, false, true},
+    {"mfma_p1m2", launch_std_mfma<1, 2>, false, true}, // generic: pre-quantisation dump
+    {"valu", launch_std_valu, false, true},             // the reference-shaped one-pixel-per-thread kernel: exactness anchor
+    {"vfma", launch_std_vfma, false, true},             // the non-tensor wavefront kernel
+};
+const int kNumTenVariants = sizeof(kTenVariants) / sizeof(kTenVariants[0]);
+const int kNumStdVariants = sizeof(kStdVariants) / sizeof(kStdVariants[0]);
+int find_variant(const Variant *table, int n, const char *name)
+{
+    for(int i = 0; i < n; i++)
+        if(std::strcmp(table[i].name, name) == 0)
+            return i;
+    return 0;
+}
+// the generic kernels: plain fp32 epilogue, any weights, pre-quantisation dump, per-batch rounding (TEN_WM)
+const int kGenericTenVariant = find_variant(kTenVariants, kNumTenVariants, "direct_p1m2");
+const int kGenericStdVariant = find_variant(kStdVariants, kNumStdVariants, "mfma_p1m2");
+
+int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a);
+
+int check_render_args(lfi_ctx *c, int method, int v0, int v1)
+{
+    if(!c)
+        return LFI_EINVAL;
+    if(!c->grid)
+        return fail(c, LFI_EINVAL, "lfi_set_grid has not been called");
+    if(!c->have_params)
+        return fail(c, LFI_EINVAL, "lfi_set_params has not been called");
+    if(method != LFI_METHOD_STD && method != LFI_METHOD_TEN_WM)
+        return fail(c, LFI_EINVAL, "The specified interpolation method does not exist!");
+    if(v0 < 0 || v1 > c->views_n || v0 >= v1)
+        return fail(c, LFI_EINVAL, "view range [v0, v1) outside [0, views)");
+    return LFI_OK;
+}
+
+// Consecutive launches over the same inputs (the reference's 100-launch loop, a trajectory streamed in blocks, a focus sweep) walk
+// the tiles in opposite directions: the input rows a launch read last are the ones the next launch reads first, so part of them
+// is still in the 256 MB Infinity Cache (config 2: −7 %, profiles/r02_p3_alternate.txt).  Same work, same bytes requested; fewer
+// of them come from HBM.  LFI_FLAG_SINGLE_SWEEP_DIRECTION turns it off (every launch ascending, as a cold launch behaves).
+int next_sweep_direction(const lfi_ctx *c)
+{
+    if(c->flags & LFI_FLAG_SINGLE_SWEEP_DIRECTION)
+        return 0;
+    return int(c->sweep_launches++ & 1u);
+}
+
+
+// Make the planar copy of the inputs valid for a fixed-focus launch with the current parameters; returns false (and leaves the
+// launch on the RGBA planes) when the copy may not be used: inputs the library cannot track, absurd offsets.
+bool ensure_planar(lfi_ctx *c)
+{
+    if(!c->grid_tracked)
+        return false;
+    const int reach = std::max(std::max(std::abs(c->fo_min[0]), std::abs(c->fo_max[0])), 0);
+    if(reach > 4 * c->width + 4096)
+        return false;
+    // a tile's 128-byte run may start `reach` pixels left of column 0 and, for the ragged last tile of a row, end 127 pixels past
+    // the row plus `reach`: pad by reach + 128 on both sides
+    const int need = (reach + 128 + 3) / 4 * 4;
+    if(c->planar && c->planar_version == c->grid_version && c->planar_padx >= need)
+        return true;
+    const int padx = std::max(need, c->planar_padx);
+    const int pitch = (c->width + 2 * padx + 15) / 16 * 16;
+    // blend_p3 addresses a row as (shift·rows + row)·pitch with 24-bit multiplies, and a lane's byte inside its octet of images (8
+    // images × 12 planes) with 32 bits
+    if(c->in_rows >= (1 << 22) || pitch >= (1 << 24) || (uint64_t)100 * c->in_rows * pitch >= (1ull << 32))
+        return false;
+    const size_t bytes = (size_t)c->n * 12 * c->in_rows * pitch; // the rows this context holds (a row window: band + halo)
+    if(bytes != c->planar_bytes)
+    {
+        if(c->planar)
+            (void)hipFree(c->planar);
+        c->planar = nullptr;
+        c->planar_bytes = 0;
+        c->planar_version = 0;
+        if(hipMalloc(reinterpret_cast<void **>(&c->planar), bytes) != hipSuccess)
+        {
+            (void)hipGetLastError(); // not enough memory for the copy: render from the RGBA planes
+            c->planar = nullptr;
+            return false;
+        }
+        c->planar_bytes = bytes;
+    }
+    c->planar_padx = padx;
+    c->planar_pitch = pitch;
+    hipLaunchKernelGGL(lfi::planar_build, dim3((pitch / 4 + 255) / 256, c->in_rows, c->n), dim3(256), 0, c->stream, c->grid, c->planar,
+                       c->width, c->in_rows, pitch, padx);
+    if(hipGetLastError() != hipSuccess)
+        return false;
+    c->planar_version = c->grid_version;
+    return true;
+}
+
+// Would this launch read the planar copy of the inputs?  It pays where reads are a large share of the traffic: not for launches
+// that write many more views than they read images (config 4 on one GPU, 256 views from 64 images: +6 % — the byte-wise operand
+// assembly repeats per view pass).
+bool wants_planar(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
+{
+    if(all_focus || a.prequant || !c->weights_scalable || a.v1 - a.v0 > std::max(c->n, 64))
+        return false;
+    if(method == LFI_METHOD_TEN_WM)
+        return kTenVariants[c->ten_variant].planar && !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH);
+    // STD: blend_planar<STDF> — one chunk, and weights for which its error bounds hold
+    return method == LFI_METHOD_STD && kStdVariants[c->std_variant].planar && c->weights_sum_ok && a.k_pad <= 64;
+}
+
+// planar view layout: does blend_p3 serve this launch?  (TEN_WM, fixed focus, weights in [0, 2) for the packed epilogue, no
+// debug modes; the planar input copy must be usable)
+bool wants_p3(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
+{
+    // blend_p3's epilogue addresses a wave's 48 byte planes (16 views × 3 channels) with one 32-bit per-lane offset
+    const bool planes_fit = (uint64_t)48 * (uint64_t)c->out_rows * (uint64_t)view_pitch(c) < (1ull << 32);
+    return c->out_layout == LFI_LAYOUT_PLANAR_RGB && method == LFI_METHOD_TEN_WM && !all_focus && !a.prequant && c->weights_scalable &&
+           !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) && kTenVariants[c->ten_variant].planar && a.k_pad <= 4 * lfi::P3_KC && planes_fit;
+}
+
+// Does a render with these arguments read the derived planar copy of the inputs?  ONE predicate for launch_blend's two branches,
+// lfi_prepare and lfi_benchmark (round 2: lfi_prepare tested wants_planar only and built nothing for launches that blend_p3 serves
+// beyond wants_planar's view limit — 256 views from 64 images — so the first render carried the build).
+bool wants_derived_copy(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
+{
+    // planar views: blend_p3 where it serves the launch; everything else — and every launch of the RGBA layout — goes through
+    // launch_blend_rgba, whose kernels read the copy under wants_planar's conditions
+    return (c->out_layout == LFI_LAYOUT_PLANAR_RGB && wants_p3(c, method, all_focus, a)) || wants_planar(c, method, all_focus, a);
+}
+
+void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
+{
+    const int tiles_x = (a_in.width + lfi::P3_TPX - 1) / lfi::P3_TPX;
+    const int n_tiles = tiles_x * a_in.out_rows;
+    const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+    const int nch = (a_in.k_pad + lfi::P3_KC - 1) / lfi::P3_KC;
+    note_kernel(c, "blend_p3<TEN_WM>");
+#ifdef LFI_MEASUREMENT_BUILD
+    // measurement builds only (make HIPFLAGS+=-DLFI_MEASUREMENT_BUILD, tools/p3_ablate.py): where does a unit's time go?  The ablated
+    // kernels write garbage by construction, so the production library does not contain them and reads no such environment variable.
+    static const int ablate = [] {
+        const char *e = std::getenv("LFI_P3_ABLATE");
+        return e ? std::atoi(e) : 0;
+    }();
+    if(ablate >= 1 && ablate <= 3 && (nch == 1 || (nch == 4 && a_in.v1 - a_in.v0 <= 64)))
+    {
+        note_kernel(c, "blend_p3<ABLATION>");
+        const int abl_passes = nch == 1 ? (a_in.v1 - a_in.v0 + 63) / 64 : 1;
+#define LFI_P3_ABL(N, A) hipLaunchKernelGGL((lfi::blend_p3<true, N, A, (N == 1 ? 1 : 2)>), grid, dim3(N == 1 ? 256 : 128), 0, stream_of(c), a_in, tiles_x, n_tiles, abl_passes, 0)
+        if(nch == 1)
+        {
+            if(ablate == 1) LFI_P3_ABL(1, 1); else if(ablate == 2) LFI_P3_ABL(1, 2); else LFI_P3_ABL(1, 3);
+        }
+        else
+        {
+            if(ablate == 1) LFI_P3_ABL(4, 1); else if(ablate == 2) LFI_P3_ABL(4, 2); else LFI_P3_ABL(4, 3);
+        }
+#undef LFI_P3_ABL
+        return;
+    }
+#endif
+    const int reverse = next_sweep_direction(c);
+    // Views per wave: 16 (four waves per workgroup, two per SIMD) when the launch is paced by its memory pipeline — one chunk of
+    // images — and 32 (two waves per workgroup, one per SIMD, the pixel operand built once for two MFMAs) when several chunks make the
+    // k-loop the pacer (15×15 grids: −13 % at 4K, profiles/r02_p3_vg.txt).  LFI_P3_VG = 1 / 2 forces either (measurements only).
+    static const int vg_env = [] {
+        const char *e = std::getenv("LFI_P3_VG");
+        return e ? std::atoi(e) : 0;
+    }();
+    const dim3 block2(128);
+    if(nch == 1)
+    {
+        // one chunk of images: every 64-view pass of a tile reads the same LDS-resident pixels (inputs fetched once per launch)
+        const int passes = (a_in.v1 - a_in.v0 + 63) / 64;
+        if(vg_env == 2)
+            hipLaunchKernelGGL((lfi::blend_p3<true, 1, 0, 2>), grid, block2, 0, stream_of(c), a_in, tiles_x, n_tiles, passes, reverse);
+        else
+            hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a_in, tiles_x, n_tiles, passes, reverse);
+        return;
+    }
+    // several chunks: one launch per 64 views
+    for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 64)
+    {
+        KernelArgs a = a_in;
+        a.v0 = v0;
+        a.v1 = std::min(v0 + 64, a_in.v1);
+#define LFI_P3_LAUNCH(N)                                                                                                                        \
+    if(vg_env == 1)                                                                                                                             \
+        hipLaunchKernelGGL((lfi::blend_p3<true, N, 0, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse);                        \
+    else                                                                                                                                        \
+        hipLaunchKernelGGL((lfi::blend_p3<true, N, 0, 2>), grid, block2, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse)
+        switch(nch)
+        {
+            case 2: LFI_P3_LAUNCH(2); break;
+            case 3: LFI_P3_LAUNCH(3); break;
+            default: LFI_P3_LAUNCH(4); break;
+        }
+#undef LFI_P3_LAUNCH
+    }
+}
+
+int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in);
+
+int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
+{
+    if(int rc = join_uploads(c))
+        return rc;
+    if(c->out_layout != LFI_LAYOUT_PLANAR_RGB)
+        return launch_blend_rgba(c, method, all_focus, a_in);
+    if(wants_p3(c, method, all_focus, a_in) && ensure_planar(c))
+    {
+        KernelArgs a = a_in;
+        a.planar = c->planar;
+        a.planar_pitch = c->planar_pitch;
+        a.planar_padx = c->planar_padx;
+        launch_p3(c, a);
+        LFI_HIP(c, hipGetLastError());
+        return LFI_OK;
+    }
+    // every other render (STD, all-focus, debug modes, weights outside [0, 2)) goes through the RGBA kernels into a scratch copy of
+    // the views and is converted to byte planes afterwards
+    const size_t need = rgba_out_plane_bytes(c) * c->views_n;
+    if(c->rgba_scratch_bytes != need)
+    {
+        if(c->rgba_scratch)
+            (void)hipFree(c->rgba_scratch);
+        c->rgba_scratch = nullptr;
+        c->rgba_scratch_bytes = 0;
+        LFI_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->rgba_scratch), need));
+        c->rgba_scratch_bytes = need;
+    }
+    KernelArgs a = a_in;
+    a.views = c->rgba_scratch;
+    if(int rc = launch_blend_rgba(c, method, all_focus, a))
+        return rc;
+    const int pitch = view_pitch(c);
+    hipLaunchKernelGGL(lfi::views_rgba_to_planar, dim3((pitch / 4 + 255) / 256, c->out_rows, a.v1 - a.v0), dim3(256), 0, c->stream,
+                       reinterpret_cast<const uint32_t *>(c->rgba_scratch + rgba_out_plane_bytes(c) * a.v0), c->views + out_plane_bytes(c) * a.v0,
+                       c->width, c->out_rows, pitch);
+    LFI_HIP(c, hipGetLastError());
+    return LFI_OK;
+}
+
+int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
+{
+    KernelArgs a = a_in;
+    if(wants_planar(c, method, all_focus, a) && ensure_planar(c))
+    {
+        a.planar = c->planar;
+        a.planar_pitch = c->planar_pitch;
+        a.planar_padx = c->planar_padx;
+    }
+    if(c->windowed)
+    {
+        // a row window is honoured by the persistent kernels only
+        const bool ten = method == LFI_METHOD_TEN_WM;
+        const Variant &v = ten ? kTenVariants[c->ten_variant] : kStdVariants[c->std_variant];
+        if(a.prequant || !v.row_window || (c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) || (ten && v.packed_epilogue && !c->weights_scalable))
+            return fail(c, LFI_EINVAL, "with a row window only renders with the default (persistent) kernels and weights in [0,2) are supported");
+        if(all_focus)
+        {
+            // every image row an all-focus render of the band can sample must be held: (int)fma(f, offset.y, y) for f between the
+            // ends of the focus range (the map decodes to focus + m/255·range), y in the band; ±1 for float rounding
+            const float f_lo = std::min(c->focus, c->focus + c->range), f_hi = std::max(c->focus, c->focus + c->range);
+            for(const lfi_float2 &o : c->h_offsets)
+            {
+                const double d_lo = std::min((double)f_lo * o.y, (double)f_hi * o.y), d_hi = std::max((double)f_lo * o.y, (double)f_hi * o.y);
+                const int H = c->height;
+                const int lo = std::min(std::max((int)std::floor(c->out_y0 + d_lo) - 1, 0), H - 1);
+                const int hi = std::min(std::max((int)std::ceil(c->out_y0 + c->out_rows - 1 + d_hi) + 1, 0), H - 1);
+                if(lo < c->in_y0 || hi >= c->in_y0 + c->in_rows)
+                    return fail(c, LFI_EINVAL, "the input row window does not cover the rows an all-focus render of this band samples");
+            }
+        }
+    }
+    if(method == LFI_METHOD_TEN_WM)
+    {
+        // the generic kernel (direct_p1m2) serves what the packed-epilogue kernels cannot: the per-batch rounding debug
+        // mode, pre-quantisation dumps, and weights outside [0, 2)
+        int variant = c->ten_variant;
+        if((c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) || (kTenVariants[variant].packed_epilogue && !c->weights_scalable) ||
+           (a.prequant && !kTenVariants[variant].prequant))
+            variant = kGenericTenVariant;
+        kTenVariants[variant].launch(c, a, all_focus != 0);
+    }
+    else if(method == LFI_METHOD_STD)
+    {
+        int variant = c->std_variant;
+        if(a.prequant && !kStdVariants[variant].prequant)
+            variant = kGenericStdVariant;
+        kStdVariants[variant].launch(c, a, all_focus != 0);
+    }
+    else
+        // the reference throws here (src/interpolator.cu:289-290)
+        return fail(c, LFI_EINVAL, "The specified interpolation method does not exist!");
+    LFI_HIP(c, hipGetLastError());
+    return LFI_OK;
+}
+
+// device pointer and pitch of view v as an RGBA plane of out_rows rows: the view itself, or (planar layout) its expansion into the
+// context's one-plane staging buffer — valid until the next call, ordered on the context's stream
+int rgba_plane_of_view(lfi_ctx *c, int v, const uint8_t **out)
+{
+    if(c->out_layout != LFI_LAYOUT_PLANAR_RGB)
+    {
+        *out = c->views + out_plane_bytes(c) * v;
+        return LFI_OK;
+    }
+    const size_t need = rgba_out_plane_bytes(c);
+    if(c->dl_plane_bytes != need)
+    {
+        if(c->dl_plane)
+            (void)hipFree(c->dl_plane);
+        c->dl_plane = nullptr;
+        c->dl_plane_bytes = 0;
+        LFI_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->dl_plane), need));
+        c->dl_plane_bytes = need;
+    }
+    hipLaunchKernelGGL(lfi::view_planar_to_rgba, dim3(((c->width + 3) / 4 + 255) / 256, c->out_rows), dim3(256), 0, c->stream,
+                       c->views + out_plane_bytes(c) * v, reinterpret_cast<uint32_t *>(c->dl_plane), c->width, c->out_rows, view_pitch(c));
+    LFI_HIP(c, hipGetLastError());
+    *out = c->dl_plane;
+    return LFI_OK;
+}
+
+} // namespace

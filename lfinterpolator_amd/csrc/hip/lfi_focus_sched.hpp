@@ -1,0 +1,142 @@
+// lfi_focus_sched.hpp — scheduling of the focus-map estimate: the factored pipeline's workspace and its two-stream pass graph
+// (focus_factored.hpp), and the choice between it, the row-window path and the other estimate variants.
+// Replaces the FocusMap::estimate / FocusMap::filter launches (reference src/interpolator.cu:261-266).
+// Included by lfi_hip.hip only (one translation unit), after lfi_context.hpp.
+#pragma once
+
+#include "lfi_context.hpp"
+#include "focus_factored.hpp"
+
+namespace {
+
+// the factored estimate (focus_factored.hpp): carve the workspace, then plan → pad → E → exact keys → pick.
+// Returns LFI_OK with *done = false when the padded planes would be unreasonably large (the caller takes another variant).
+int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
+{
+    *done = false;
+    const int W = ctx->width, H = ctx->height, rx = ctx->radius[0], ry = ctx->radius[1];
+    lfi::FocusWork w{};
+    w.We_p = (W + 2 * rx + 255) / 256 * 256;
+    w.He_p = (H + 2 * ry + 3) / 4 * 4;
+    // largest |shift| any candidate gives any sampled image: candidates are monotone in i, so the ends bound them
+    const float step = ctx->range / 31.0f;
+    const double fmax = std::max(std::fabs((double)ctx->focus), std::fabs((double)std::fmaf(step, 31.0f, ctx->focus)));
+    double ox = 0, oy = 0;
+    for(const lfi_float2 &o : ctx->h_focus_offsets)
+    {
+        ox = std::max(ox, std::fabs((double)o.x));
+        oy = std::max(oy, std::fabs((double)o.y));
+    }
+    if(!(fmax * ox < 1e6 && fmax * oy < 1e6))
+        return LFI_OK;
+    const int Sx = (int)std::ceil(fmax * ox) + 1, Sy = (int)std::ceil(fmax * oy) + 1; // ≥ |floor(δ)| and ≥ |floor(δ)+1|
+    w.Px = Sx + rx;
+    w.Py = Sy + ry;
+    w.Wp = (w.Px + std::max(W + Sx + rx, w.We_p - rx + Sx) + 3) / 4 * 4;
+    w.Hp = w.Py + std::max(H + Sy + ry, w.He_p - ry + Sy);
+    const size_t pad_bytes = sizeof(uint32_t) * (size_t)ctx->n_focus_ids * w.Hp * w.Wp;
+    if(pad_bytes > ((size_t)16 << 30))
+        return LFI_OK;
+    size_t at = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t here = at;
+        at += (bytes + 255) / 256 * 256;
+        return here;
+    };
+    const size_t o_shifts = carve(sizeof(int32_t) * 4 * lfi::FOCUS_STEPS * lfi::FOCUS_MAX_IDS);
+    const size_t o_badx = carve(sizeof(uint32_t) * W), o_bady = carve(sizeof(uint32_t) * H);
+    const size_t o_cols = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * W), o_rows = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * H);
+    const size_t o_ncols = carve(sizeof(int32_t) * lfi::FOCUS_STEPS), o_nrows = carve(sizeof(int32_t) * lfi::FOCUS_STEPS);
+    const size_t o_prefix = carve(sizeof(uint32_t) * 3 * 33);
+    const size_t o_rowbase = carve(sizeof(uint32_t) * H), o_colbase = carve(sizeof(uint32_t) * (W + 1));
+    // line buffers for 4× the typical number of flagged rows / columns (three bands of r per candidate ≈ 0.03·H each);
+    // anything beyond takes the tap-by-tap path
+    w.R_cap = 4 * H;
+    w.C_cap = 4 * W;
+    const size_t o_Er = carve(sizeof(uint16_t) * (size_t)w.R_cap * 3 * w.We_p);
+    const size_t o_Ec = carve(sizeof(uint16_t) * (size_t)w.C_cap * 3 * w.He_p);
+    const size_t o_E = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * (size_t)w.He_p * w.We_p);
+    const size_t o_K = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * (size_t)H * W);
+    const size_t o_deltas = carve(sizeof(int64_t) * lfi::FOCUS_STEPS * lfi::FOCUS_MAX_IDS);
+    const size_t o_pad = carve(pad_bytes);
+    if(ctx->focus_ws_bytes != at)
+    {
+        if(ctx->focus_ws)
+            (void)hipFree(ctx->focus_ws);
+        ctx->focus_ws = nullptr;
+        ctx->focus_ws_bytes = 0;
+        LFI_HIP(ctx, hipMalloc(&ctx->focus_ws, at));
+        ctx->focus_ws_bytes = at;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->focus_ws);
+    w.shifts = reinterpret_cast<int32_t *>(base + o_shifts);
+    w.badx = reinterpret_cast<uint32_t *>(base + o_badx);
+    w.bady = reinterpret_cast<uint32_t *>(base + o_bady);
+    w.cols = reinterpret_cast<uint16_t *>(base + o_cols);
+    w.rows = reinterpret_cast<uint16_t *>(base + o_rows);
+    w.ncols = reinterpret_cast<int32_t *>(base + o_ncols);
+    w.nrows = reinterpret_cast<int32_t *>(base + o_nrows);
+    w.prefix = reinterpret_cast<uint32_t *>(base + o_prefix);
+    w.rowbase = reinterpret_cast<uint32_t *>(base + o_rowbase);
+    w.colbase = reinterpret_cast<uint32_t *>(base + o_colbase);
+    w.Er = reinterpret_cast<uint16_t *>(base + o_Er);
+    w.Ec = reinterpret_cast<uint16_t *>(base + o_Ec);
+    w.E = reinterpret_cast<uint16_t *>(base + o_E);
+    w.K = reinterpret_cast<uint16_t *>(base + o_K);
+    w.deltas = reinterpret_cast<int64_t *>(base + o_deltas);
+    w.pad = reinterpret_cast<uint32_t *>(base + o_pad);
+    // Two streams: the plan and the flagged-pair passes are small, latency-bound kernels; they run beside the padded copy
+    // and the range pass (bandwidth / VALU bound) instead of in front of them.
+    //   main:  plan_shifts ─┬─ pad ─┬─ range ───────────────────────────────┬─ pick (→ filter, by the caller)
+    //   aux:                └─ flags → lists → prefix ─┴─ {lines_rows, lines_cols, exact} → line_keys ─────┘
+    if(!ctx->aux_stream)
+    {
+        int prio_low = 0, prio_high = 0; // numerically lower = higher priority: the small passes should not queue behind the big ones
+        LFI_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        LFI_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, prio_high));
+        LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pad, hipEventDisableTiming));
+        LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    hipStream_t st = ctx->stream;
+    hipStream_t aux = ctx->aux_stream;
+    // host launch order = the critical path first: the main stream's kernels are enqueued before the side stream's
+    hipLaunchKernelGGL(lfi::focus_plan_shifts, dim3(1), dim3(1024), 0, st, a, w);
+    LFI_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+    hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, ctx->n_focus_ids), dim3(64), 0, st, a, w);
+    LFI_HIP(ctx, hipEventRecord(ctx->ev_pad, st));
+    const uint32_t tiles_x = uint32_t(w.We_p / 256), tiles_y = uint32_t(w.He_p / 4);
+    {
+        constexpr int CPW = 4, GROUPS = lfi::FOCUS_STEPS / CPW;
+        const int striped = tiles_x >= 8;
+        const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(tiles_x, tiles_y, GROUPS) : tiles_x * tiles_y * GROUPS;
+        hipLaunchKernelGGL(lfi::focus_range<CPW>, dim3(nblocks), dim3(256), 0, st, a, w, nblocks, striped);
+    }
+    LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_fork, 0));
+    LFI_HIP(ctx, hipMemsetAsync(w.badx, 0, o_cols - o_badx, aux)); // badx and bady are adjacent
+    hipLaunchKernelGGL(lfi::focus_plan_flags, dim3((std::max(W, H) + 255) / 256, lfi::FOCUS_STEPS, 2), dim3(256), 0, aux, a, w);
+    hipLaunchKernelGGL(lfi::focus_plan_lists, dim3(lfi::FOCUS_STEPS, 2), dim3(64), 0, aux, a, w);
+    hipLaunchKernelGGL(lfi::focus_plan_prefix, dim3(1), dim3(1), 0, aux, a, w);
+    LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_pad, 0));
+    {
+        const uint32_t per_pass = uint32_t(ctx->cu_count) * 4u / 8u * 8u;
+        hipLaunchKernelGGL(lfi::focus_flagged, dim3(3 * per_pass), dim3(256), 0, aux, a, w, per_pass);
+    }
+    hipLaunchKernelGGL(lfi::focus_line_keys, dim3(ctx->cu_count * 8), dim3(256), 0, aux, a, w);
+    LFI_HIP(ctx, hipEventRecord(ctx->ev_join, aux));
+    LFI_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+    {
+        // two pixels per lane need dword-aligned sample pairs: even radius_x (the reference's is)
+        const int ppl = (rx % 2 == 0 && W >= 2) ? 2 : 1;
+        const uint32_t nblocks = uint32_t((W + 64 * ppl - 1) / (64 * ppl)) * uint32_t((H + 3) / 4);
+        if(ppl == 2)
+            hipLaunchKernelGGL(lfi::focus_pick<2>, dim3(nblocks), dim3(256), 0, st, a, w);
+        else
+            hipLaunchKernelGGL(lfi::focus_pick<1>, dim3(nblocks), dim3(256), 0, st, a, w);
+    }
+    LFI_HIP(ctx, hipGetLastError());
+    *done = true;
+    return LFI_OK;
+}
+
+} // namespace

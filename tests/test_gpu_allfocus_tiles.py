@@ -118,6 +118,9 @@ def test_structured_map_row_bands(world, gpu, oracle_c):
         full.sync()
         want[method] = full.download_views()
     full.close()
+    # the checker is the oracle: STD bit-exact, TEN_WM within one LSB of M16 (both maps hold the same plane here)
+    oracle_views = {"STD": oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, all_focus=True, map_plane=m, focus=hp.focus, rng=hp.range, threads=8),
+                    "TEN_WM": oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, all_focus=True, map_plane=m, focus=hp.focus, rng=hp.range, threads=8)}
     for method in ("STD", "TEN_WM"):
         got = np.zeros_like(want[method])
         for rank in range(world):
@@ -134,4 +137,8 @@ def test_structured_map_row_bands(world, gpu, oracle_c):
             ctx.sync()
             got |= ctx.download_views()
             ctx.close()
+        if method == "STD":
+            assert (got == oracle_views["STD"]).all(), "structured-map row bands: STD differs from the oracle"
+        else:
+            assert np.abs(got.astype(int) - oracle_views["TEN_WM"].astype(int)).max() <= TEN_TOL_LSB
         assert (got == want[method]).all(), method

@@ -252,6 +252,10 @@ def test_row_band_sharding_matches_full_render(world, gpu, oracle_c):
     W, H, V = 200, 96, 64
     hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.1, 0.0, 3.0, 1.783, V)
     lf = oracle_c.synthetic_lf(64, W, H, SEED)
+    # the checker is the ORACLE (STD bit-exact, TEN_WM within one LSB of M16); the library's own full render is compared too, byte for
+    # byte — a band must not depend on how the image is split — but a coordinate error shared by both paths would pass that alone
+    oracle_views = {"STD": oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, threads=8),
+                    "TEN_WM": oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, model=oracle_c.TEN_M16, threads=8)}
     full = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
     for method in ("STD", "TEN_WM"):
         full.render(method)
@@ -279,6 +283,10 @@ def test_row_band_sharding_matches_full_render(world, gpu, oracle_c):
             got |= part
             ctx.close()
         assert (got == want).all(), method
+        if method == "STD":
+            assert (got == oracle_views["STD"]).all(), "row bands: STD differs from the oracle"
+        else:
+            assert np.abs(got.astype(int) - oracle_views["TEN_WM"].astype(int)).max() <= TEN_TOL_LSB, "row bands: TEN_WM differs from M16"
         assert max(held) < H
     if True:
         # an input window that misses sampled rows is refused
@@ -518,6 +526,22 @@ def test_std_rounding_band_adversarial(kind, gpu, oracle_c):
     ctx.close()
 
 
+def test_std_analytic_band_flag(gpu, oracle_c):
+    """LFI_FLAG_STD_ANALYTIC_BAND sizes the band of blend_planar<STDF> with the analytic accumulation bound (a whole ulp per addend)
+    instead of the measured one: same kernel, same bytes, more sums recomputed — bit-exact like the default."""
+    cols, rows, W, H, V = 8, 8, 300, 5, 64
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.1, 0.0, 3.0, 1.783, V)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, 21)
+    want = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights)
+    for flags in (0, gpu.LFI_FLAG_STD_ANALYTIC_BAND):
+        ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf, flags=flags)
+        ctx.render("STD")
+        ctx.sync()
+        assert ctx.last_kernel_name() == "blend_planar<STDF>"
+        assert (ctx.download_views() == want).all(), flags
+        ctx.close()
+
+
 def _exact_products(a_bits, b_bits):
     """Exact A·B of fp16 bit patterns as Python integers scaled by 2^48 (every fp16 is an integer multiple of 2^-24)."""
     a = (a_bits.view(np.float16).astype(np.float64) * 2.0 ** 24).astype(object)
@@ -673,6 +697,14 @@ def test_row_band_sharding_all_focus(world, gpu, oracle_c):
             got[method] |= ctx.download_views()
         ctx.close()
     assert (got_map1 == want_maps[1]).all()
+    # against the oracle: both maps of the bands, STD bit-exact from map 1, TEN_WM within one LSB from map 0 (src/kernels.cu:326, :430)
+    o_map0 = oracle_c.focus_estimate(lf, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, threads=8)
+    o_map1 = oracle_c.focus_filter(o_map0, hp.block_radius)
+    assert (want_maps[0] == o_map0).all() and (got_map1 == o_map1).all()
+    o_std = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, all_focus=True, map_plane=o_map1, focus=hp.focus, rng=hp.range, threads=8)
+    o_ten = oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, all_focus=True, map_plane=o_map0, focus=hp.focus, rng=hp.range, threads=8)
+    assert (got["STD"] == o_std).all(), "all-focus row bands: STD differs from the oracle"
+    assert np.abs(got["TEN_WM"].astype(int) - o_ten.astype(int)).max() <= TEN_TOL_LSB, "all-focus row bands: TEN_WM differs from M16"
     for method in want:
         assert (got[method] == want[method]).all(), method
     assert max(held) < H or world == 2

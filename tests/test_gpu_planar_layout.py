@@ -136,13 +136,18 @@ def test_planar_layout_weights_outside_unit_range_fall_back(gpu, oracle_c):
     ctx.close()
 
 
-@pytest.mark.parametrize("world,cols", [(2, 8), (3, 8), (2, 15), (3, 11)])
-def test_planar_layout_row_bands(world, cols, gpu, oracle_c):
+@pytest.mark.parametrize("world,cols,W", [(2, 8, 200), (3, 8, 203), (2, 15, 200), (3, 11, 131)])
+def test_planar_layout_row_bands(world, cols, W, gpu, oracle_c):
     """Row-band sharding in the planar layout: every band renders its rows of every view from the input rows it holds — with one chunk
-    of images (four waves of 16 views per workgroup) and with several (two waves of 32 views)."""
+    of images (four waves of 16 views per workgroup) and with several (two waves of 32 views); ragged widths (203, 131: not a
+    multiple of the 16-byte view pitch); the first and last bands' halos clamp at the image edges (offsets reach beyond them).
+    Checked against the ORACLE (≤ 1 LSB of M16) and, byte for byte, against the library's unsharded RGBA render."""
     rows = cols
-    W, H, V = 200, 96, 64 if cols == 8 else 40
+    H, V = 96, 64 if cols == 8 else 40
     hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.1, 0.0, 3.0, 1.783, V)
+    assert hp.focused_offsets[:, 1].min() < 0 < hp.focused_offsets[:, 1].max()    # rows above row 0 / below row H − 1 are sampled
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, SEED)
+    m16 = oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, model=oracle_c.TEN_M16, threads=8)
     full = _ctx(gpu, cols, rows, W, H, hp, layout="rgba")
     full.render("TEN_WM")
     full.sync()
@@ -166,6 +171,8 @@ def test_planar_layout_row_bands(world, cols, gpu, oracle_c):
         assert (part[:, :band[0]] == 0).all() and (part[:, band[1]:] == 0).all()
         got |= part
         ctx.close()
+    assert np.abs(got.astype(int) - m16.astype(int)).max() <= TEN_TOL_LSB, "planar row bands differ from the oracle's M16"
+    assert (got[..., 3] == 255).all()
     assert (got == want).all()
 
 
