@@ -281,6 +281,11 @@ int lfi_download_prequant(lfi_ctx *ctx, int method, int all_focus, int v, float 
 /* hardware probe: C[32x32] = A[32x16] (fp16 bits) · B[16x32] (fp16 bits) with one v_mfma_f32_32x32x16_f16,
  * row-major in/out — checks the fragment lane maps and fp16-subnormal handling with exact data */
 int lfi_debug_mfma_f16(lfi_ctx *ctx, const uint16_t *a_32x16, const uint16_t *b_16x32, float *c_32x32);
+/* hardware probe: gfx950's three-operand packed fp16 minimum / maximum (v_pk_minimum3_f16 / v_pk_maximum3_f16) on u16 lanes that
+ * hold bytes, i.e. fp16 subnormal bit patterns, over all 256³ byte triples (twice: once per half) against integer min / max;
+ * *out_mismatches = the number of halves that differ (0 on hardware that leaves subnormals alone).  The focus-map range passes
+ * reduce two views per instruction with them (csrc/hip/focus_factored.hpp; FocusMap::ElementRange, src/kernels.cu:173-194). */
+int lfi_debug_pk_minmax3_f16(lfi_ctx *ctx, uint32_t *out_mismatches);
 /* hardware probe: C[32x32] = A[32xk] · B[kx32] accumulated as the kernels accumulate — shape 0: k/16 chained
  * v_mfma_f32_32x32x16_f16, shape 1: k/32 chained v_mfma_f32_16x16x32_f16 per quadrant; k a multiple of 32, ≤ 256.  Measures the
  * matrix pipe's fp32 accumulation error, which the default STD kernel's rounding band assumes a bound for. */

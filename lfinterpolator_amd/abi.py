@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
     "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
-    "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_fill_synthetic_scene", "lfi_upload_image_async", "lfi_upload_wait", "lfi_render_stream", "lfi_compare_view", "lfi_debug_mfma_f16_chain",
+    "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_fill_synthetic_scene", "lfi_upload_image_async", "lfi_upload_wait", "lfi_render_stream", "lfi_compare_view", "lfi_debug_mfma_f16_chain", "lfi_debug_pk_minmax3_f16",
 ]
 
 
@@ -126,6 +126,7 @@ def load_hip_library() -> C.CDLL:
         "lfi_upload_wait": (i, [vp]),
         "lfi_fill_synthetic_scene": (i, [vp, C.c_uint32]),
         "lfi_debug_mfma_f16_chain": (i, [vp, i, i, vp, vp, vp]),
+        "lfi_debug_pk_minmax3_f16": (i, [vp, vp]),
         "lfi_set_output_layout": (i, [vp, i]),
         "lfi_view_layout": (i, [vp, C.POINTER(ViewLayout)]),
         "lfi_fill_synthetic_images": (i, [vp, C.c_uint32, i, i]),
@@ -423,6 +424,12 @@ class Context:
         c = np.empty((32, 32), dtype=np.float32)
         self._check(self._lib.lfi_debug_mfma_f16_chain(self._h, shape, k, _ptr(a), _ptr(b), _ptr(c)))
         return c
+
+    def debug_pk_minmax3_f16(self) -> int:
+        """Mismatching halves of v_pk_minimum3_f16 / v_pk_maximum3_f16 against integer min / max over all byte triples."""
+        out = C.c_uint32(0xffffffff)
+        self._check(self._lib.lfi_debug_pk_minmax3_f16(self._h, C.byref(out)))
+        return int(out.value)
 
     def debug_mfma_f16(self, a_bits: np.ndarray, b_bits: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(a_bits, dtype=np.uint16)

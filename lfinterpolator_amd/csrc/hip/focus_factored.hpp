@@ -206,6 +206,48 @@ __global__ void focus_plan_prefix(const KernelArgs a, const FocusWork w)
     w.prefix[98] = chunks;
 }
 
+// Two samples per instruction.  A u16 lane that holds a byte (0 … 255) is the bit pattern of a non-negative fp16 SUBNORMAL, and the
+// float order of non-negative fp16 values is the integer order of their bit patterns, so gfx950's three-operand packed fp16
+// minimum / maximum (v_pk_minimum3_f16 / v_pk_maximum3_f16: IEEE-754-2019 minimum / maximum, no NaN can occur) reduce (accumulator,
+// sample of view k, sample of view k + 1) to the same bytes as two v_pk_min_u16 / v_pk_max_u16 would — IF the instructions leave
+// subnormals alone: kernels are compiled with fp16 denormals enabled (.amdhsa_float_denorm_mode_16_64 3) and lfi_debug_pk_minmax3_f16
+// checks all 256³ byte triples on the device (tests/test_gpu_parity.py::test_pk_minmax3_f16_on_bytes).  Round 2's range pass issued
+// 12 packed min / max per four pixels and view (VALU-issue-bound, profiles/r02_pmc_focus_range_summary.txt); this issues 6.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 min3_bytes(const u16x2 acc, const u16x2 a, const u16x2 b)
+{
+    // written as a CHAIN ((acc ∧ a) ∧ b): the instruction selector folds a chain link by link into minimum3; written as acc ∧ (a ∧ b)
+    // two consecutive reductions became minimum3(acc, a ∧ b, c ∧ d) plus two two-operand minima — three instructions per four samples
+    const f16x2 m = __builtin_elementwise_minimum(__builtin_elementwise_minimum(__builtin_bit_cast(f16x2, acc), __builtin_bit_cast(f16x2, a)),
+                                                  __builtin_bit_cast(f16x2, b));
+    return __builtin_bit_cast(u16x2, m);
+}
+__device__ __forceinline__ u16x2 max3_bytes(const u16x2 acc, const u16x2 a, const u16x2 b)
+{
+    const f16x2 m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(f16x2, acc), __builtin_bit_cast(f16x2, a)),
+                                                  __builtin_bit_cast(f16x2, b));
+    return __builtin_bit_cast(u16x2, m);
+}
+
+// hardware probe behind lfi_debug_pk_minmax3_f16: every byte triple (a, b, c) — 2^24 threads, two triples each (one per u16 half) —
+// through min3_bytes / max3_bytes against integer min / max; counts the halves that differ
+__global__ void __launch_bounds__(256) probe_pk_minmax3(uint32_t *mismatches)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t a0 = t & 255u, b0 = (t >> 8) & 255u, c0 = (t >> 16) & 255u;
+    const uint32_t a1 = 255u - a0, b1 = b0 ^ 0x5au, c1 = (c0 * 7u + 3u) & 255u;
+    const u16x2 A = as_u16x2(a0 | (a1 << 16)), B = as_u16x2(b0 | (b1 << 16)), C = as_u16x2(c0 | (c1 << 16));
+    const uint32_t mn = as_u32(min3_bytes(C, A, B)), mx = as_u32(max3_bytes(C, A, B));
+    const uint32_t want_mn = min(min(a0, b0), c0) | (min(min(a1, b1), c1) << 16), want_mx = max(max(a0, b0), c0) | (max(max(a1, b1), c1) << 16);
+    uint32_t bad = 0;
+    bad += (mn & 0xffffu) != (want_mn & 0xffffu);
+    bad += (mn >> 16) != (want_mn >> 16);
+    bad += (mx & 0xffffu) != (want_mx & 0xffffu);
+    bad += (mx >> 16) != (want_mx >> 16);
+    if(bad)
+        atomicAdd(mismatches, bad);
+}
+
 // running per-channel min / max of FOUR consecutive pixels of a lane (two u16 pairs per channel) and the E encoding
 struct RangeAcc4
 {
@@ -236,6 +278,29 @@ struct RangeAcc4
             hi[p][1] = __builtin_elementwise_max(hi[p][1], cg);
             lo[p][2] = __builtin_elementwise_min(lo[p][2], cb);
             hi[p][2] = __builtin_elementwise_max(hi[p][2], cb);
+        }
+    }
+    // the samples of TWO views at once (min3 / max3)
+    __device__ __forceinline__ void add2(const u32x4 va, const u32x4 vb)
+    {
+#ifdef LFI_AB_NO_MINMAX3 // measurement builds: the same loops with round 2's two-operand u16 reductions (A/B on one box)
+        add(va);
+        add(vb);
+        return;
+#endif
+        const uint32_t pa[4] = {va.x, va.y, va.z, va.w}, pb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for(int p = 0; p < 2; p++)
+        {
+            const u16x2 ar = channel_pair<0>(pa[2 * p], pa[2 * p + 1]), br = channel_pair<0>(pb[2 * p], pb[2 * p + 1]);
+            const u16x2 ag = channel_pair<1>(pa[2 * p], pa[2 * p + 1]), bg = channel_pair<1>(pb[2 * p], pb[2 * p + 1]);
+            const u16x2 ab = channel_pair<2>(pa[2 * p], pa[2 * p + 1]), bb = channel_pair<2>(pb[2 * p], pb[2 * p + 1]);
+            lo[p][0] = min3_bytes(lo[p][0], ar, br);
+            hi[p][0] = max3_bytes(hi[p][0], ar, br);
+            lo[p][1] = min3_bytes(lo[p][1], ag, bg);
+            hi[p][1] = max3_bytes(hi[p][1], ag, bg);
+            lo[p][2] = min3_bytes(lo[p][2], ab, bb);
+            hi[p][2] = max3_bytes(hi[p][2], ab, bb);
         }
     }
     // four u16: 16·range + (FLT_MIN tap ? 1 : 0), see focus_map.hpp
@@ -278,12 +343,30 @@ struct RangeAcc1
         lo_b = __builtin_elementwise_min(lo_b, b);
         hi_b = __builtin_elementwise_max(hi_b, b);
     }
+    __device__ __forceinline__ void add2(const uint32_t pa, const uint32_t pb) // two views at once (min3 / max3)
+    {
+#ifdef LFI_AB_NO_MINMAX3
+        add(pa);
+        add(pb);
+        return;
+#endif
+        const u16x2 rga = as_u16x2(__builtin_amdgcn_perm(0u, pa, 0x0c010c00u)), rgb = as_u16x2(__builtin_amdgcn_perm(0u, pb, 0x0c010c00u));
+        // B: the two halves of lo_b / hi_b are independent accumulators (`add` feeds both the same value, this feeds view a's B to the
+        // low half and view b's to the high half); result() folds them
+        const u16x2 bb = as_u16x2(__builtin_amdgcn_perm(pb, pa, 0x0c060c02u));
+        lo_rg = min3_bytes(lo_rg, rga, rgb);
+        hi_rg = max3_bytes(hi_rg, rga, rgb);
+        lo_b = __builtin_elementwise_min(lo_b, bb);
+        hi_b = __builtin_elementwise_max(hi_b, bb);
+    }
     __device__ __forceinline__ void result(uint32_t &range, uint32_t &flt_min_tap) const
     {
-        const uint32_t d_rg = as_u32(hi_rg - lo_rg), d_b = as_u32(hi_b - lo_b) & 0xffffu;
+        const uint32_t hb = as_u32(hi_b), lb = as_u32(lo_b);
+        const uint32_t hi_bv = max(hb & 0xffffu, hb >> 16), lo_bv = min(lb & 0xffffu, lb >> 16);
+        const uint32_t d_rg = as_u32(hi_rg - lo_rg), d_b = hi_bv - lo_bv;
         range = max(max(d_rg & 0xffffu, d_rg >> 16), d_b);
         const uint32_t h_rg = as_u32(hi_rg);
-        const uint32_t hmin = min(min(h_rg & 0xffffu, h_rg >> 16), as_u32(hi_b) & 0xffffu);
+        const uint32_t hmin = min(min(h_rg & 0xffffu, h_rg >> 16), hi_bv);
         flt_min_tap = (range | hmin) == 0u ? 1u : 0u;
     }
 };
@@ -349,25 +432,44 @@ __global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const Foc
     // No branches in the loop: past the last view the indices clamp to it — reducing a view twice changes no minimum or maximum —
     // so the compiler's vmcnt / lgkmcnt counts are exact (with conditional loads it has to assume they were not issued and waits
     // for everything).
-    int64_t dA[CPW], dB[CPW];
-    u32x4 pA[CPW], pB[CPW];
+    // Round 3: two views per reduction (RangeAcc4::add2: min3 / max3), so the pipeline moves in PAIRS of views: the samples of pair
+    // j + 1 are in flight while pair j is reduced, the deltas of pair j + 2 are on their way.
+    int64_t dA[CPW], dB[CPW], dC[CPW], dD[CPW];
+    u32x4 pA[CPW], pB[CPW], pC[CPW], pD[CPW];
     const int last = n_ids - 1;
     load_deltas(0, dA);
-    load_samples(dA, pA);
     load_deltas(min(1, last), dB);
-    for(int k = 0; k < n_ids; k += 2)
+    load_samples(dA, pA);
+    load_samples(dB, pB);
+    load_deltas(min(2, last), dC);
+    load_deltas(min(3, last), dD);
+    int k = 0;
+    for(; k + 4 < n_ids; k += 4)
     {
-        load_samples(dB, pB);                 // view k + 1
-        load_deltas(min(k + 2, last), dA);
+        load_samples(dC, pC);                 // views k + 2, k + 3
+        load_samples(dD, pD);
+        load_deltas(min(k + 4, last), dA);
+        load_deltas(min(k + 5, last), dB);
 #pragma unroll
         for(int c = 0; c < CPW; c++)
-            acc[c].add(pA[c]);                // view k
-        load_samples(dA, pA);                 // view k + 2
-        load_deltas(min(k + 3, last), dB);
+            acc[c].add2(pA[c], pB[c]);        // views k, k + 1
+        load_samples(dA, pA);                 // views k + 4, k + 5
+        load_samples(dB, pB);
+        load_deltas(min(k + 6, last), dC);
+        load_deltas(min(k + 7, last), dD);
 #pragma unroll
         for(int c = 0; c < CPW; c++)
-            acc[c].add(pB[c]);                // view k + 1
+            acc[c].add2(pC[c], pD[c]);        // views k + 2, k + 3
     }
+    // tail: views k, k + 1 are loaded; k + 2, k + 3 (clamped to the last view) are not
+    load_samples(dC, pC);
+    load_samples(dD, pD);
+#pragma unroll
+    for(int c = 0; c < CPW; c++)
+        acc[c].add2(pA[c], pB[c]);
+#pragma unroll
+    for(int c = 0; c < CPW; c++)
+        acc[c].add2(pC[c], pD[c]);
 #pragma unroll
     for(int c = 0; c < CPW; c++)
     {
@@ -431,23 +533,30 @@ __device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const Focu
                 for(int t = 0; t < 3; t++)
                     v[t] = *reinterpret_cast<const u32x4_a4 *>(p + t * tap_stride);
             };
-            auto reduce = [&](const u32x4 (&v)[3]) {
+            // two views per reduction (min3 / max3); past the last view the index clamps to it (reducing a view twice changes nothing)
+            auto reduce2 = [&](const u32x4 (&va)[3], const u32x4 (&vb)[3]) {
 #pragma unroll
                 for(int t = 0; t < 3; t++)
-                    acc[t].add(v[t]);
+                    acc[t].add2(va[t], vb[t]);
             };
+            const int last = n_ids - 1;
+            u32x4 cur2[3], nxt2[3];
             fetch(0, cur);
+            fetch(min(1, last), nxt);
             int k = 0;
-            for(; k + 1 < n_ids; k += 2) // two views per trip: the buffers swap roles without register moves
+            for(; k + 4 < n_ids; k += 4) // two pairs per trip: the buffers swap roles without register moves
             {
-                fetch(k + 1, nxt);
-                reduce(cur);
-                if(k + 2 < n_ids)
-                    fetch(k + 2, cur);
-                reduce(nxt);
+                fetch(k + 2, cur2);
+                fetch(k + 3, nxt2);
+                reduce2(cur, nxt);
+                fetch(k + 4, cur);
+                fetch(min(k + 5, last), nxt);
+                reduce2(cur2, nxt2);
             }
-            if(k < n_ids)
-                reduce(cur);
+            fetch(min(k + 2, last), cur2); // tail: views k, k + 1 are loaded; k + 2, k + 3 clamp to the last view
+            fetch(min(k + 3, last), nxt2);
+            reduce2(cur, nxt);
+            reduce2(cur2, nxt2);
 #pragma unroll
             for(int t = 0; t < 3; t++)
             {
@@ -515,25 +624,31 @@ __device__ __forceinline__ void focus_lines_cols(const KernelArgs &a, const Focu
                 for(int t = 0; t < 3; t++)
                     v[r][t] = *reinterpret_cast<const uint32_t *>(row + r * row_bytes + uint32_t(t * rx) * 4u + left);
         };
-        auto reduce = [&](const uint32_t (&v)[R][3]) {
+        auto reduce2 = [&](const uint32_t (&va)[R][3], const uint32_t (&vb)[R][3]) { // two views per reduction (min3 / max3)
 #pragma unroll
             for(int r = 0; r < R; r++)
 #pragma unroll
                 for(int t = 0; t < 3; t++)
-                    acc[r][t].add(v[r][t]);
+                    acc[r][t].add2(va[r][t], vb[r][t]);
         };
+        const int last = n_ids - 1;
+        uint32_t cur2[R][3], nxt2[R][3];
         fetch(0, cur);
+        fetch(min(1, last), nxt);
         int k = 0;
-        for(; k + 1 < n_ids; k += 2)
+        for(; k + 4 < n_ids; k += 4)
         {
-            fetch(k + 1, nxt);
-            reduce(cur);
-            if(k + 2 < n_ids)
-                fetch(k + 2, cur);
-            reduce(nxt);
+            fetch(k + 2, cur2);
+            fetch(k + 3, nxt2);
+            reduce2(cur, nxt);
+            fetch(k + 4, cur);
+            fetch(min(k + 5, last), nxt);
+            reduce2(cur2, nxt2);
         }
-        if(k < n_ids)
-            reduce(cur);
+        fetch(min(k + 2, last), cur2);
+        fetch(min(k + 3, last), nxt2);
+        reduce2(cur, nxt);
+        reduce2(cur2, nxt2);
         if(active)
         {
 #pragma unroll
@@ -562,22 +677,25 @@ __device__ __forceinline__ uint32_t focus_exact_key(const KernelArgs &a, const F
 #pragma unroll
     for(int t = 0; t < 9; t++)
         acc[t].init();
-    const uint8_t *plane = reinterpret_cast<const uint8_t *>(w.pad);
-    for(int k = 0; k < a.n_focus_ids; k++, plane += plane_bytes)
-    {
+    const uint8_t *pad = reinterpret_cast<const uint8_t *>(w.pad);
+    // top-left tap of view k; all nine taps are at non-negative, wave-uniform byte offsets from it
+    auto corner_of = [&](const int k) {
         const int g = c_ids[k];
         const float offx = c_offsets[2 * g], offy = c_offsets[2 * g + 1];
         const int cx = warp_float(x, f, offx), cy = warp_float(y, f, offy);
-        // top-left tap; all nine taps are at non-negative, wave-uniform byte offsets from it
-        const uint32_t corner = uint32_t((cy - ry + w.Py) * w.Wp + (cx - rx + w.Px)) * 4u;
+        return pad + (size_t)k * plane_bytes + uint32_t((cy - ry + w.Py) * w.Wp + (cx - rx + w.Px)) * 4u;
+    };
+    const int last = a.n_focus_ids - 1;
+    for(int k = 0; k <= last; k += 2) // two views per reduction (min3 / max3); an odd tail repeats the last view
+    {
+        const uint8_t *ca = corner_of(k), *cb = corner_of(min(k + 1, last));
 #pragma unroll
         for(int ty = 0; ty < 3; ty++)
 #pragma unroll
             for(int tx = 0; tx < 3; tx++)
             {
                 const uint32_t tap = uint32_t(ty * ry * w.Wp + tx * rx) * 4u;
-                const uint32_t px = *reinterpret_cast<const uint32_t *>(plane + tap + corner);
-                acc[tx * 3 + ty].add(px);
+                acc[tx * 3 + ty].add2(*reinterpret_cast<const uint32_t *>(ca + tap), *reinterpret_cast<const uint32_t *>(cb + tap));
             }
     }
     uint32_t S = 0, kmin = 0;

@@ -1203,6 +1203,29 @@ int lfi_debug_mfma_f16(lfi_ctx *ctx, const uint16_t *a_32x16, const uint16_t *b_
     return LFI_OK;
 }
 
+int lfi_debug_pk_minmax3_f16(lfi_ctx *ctx, uint32_t *out_mismatches)
+{
+    if(!ctx || !out_mismatches)
+        return LFI_EINVAL;
+    if(int rc = bind(ctx))
+        return rc;
+    uint32_t *d = nullptr;
+    LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(uint32_t), ctx->stream);
+    if(e == hipSuccess)
+    {
+        hipLaunchKernelGGL(lfi::probe_pk_minmax3, dim3(1u << 16), dim3(256), 0, ctx->stream, d);
+        e = hipGetLastError();
+    }
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(out_mismatches, d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if(e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    LFI_HIP(ctx, e);
+    return LFI_OK;
+}
+
 int lfi_debug_mfma_f16_chain(lfi_ctx *ctx, int shape, int k, const uint16_t *a_32xk, const uint16_t *b_kx32, float *c_32x32)
 {
     if(!ctx || !a_32xk || !b_kx32 || !c_32x32 || (shape != 0 && shape != 1) || k < 32 || k > 256 || k % 32)

@@ -63,6 +63,15 @@ def test_mfma_fragment_maps_and_fp16_subnormals(gpu):
     ctx.close()
 
 
+def test_pk_minmax3_f16_on_bytes(gpu):
+    """The focus-map range passes reduce two views per instruction with v_pk_minimum3_f16 / v_pk_maximum3_f16 on u16 lanes that hold
+    bytes — fp16 SUBNORMAL bit patterns, whose float order is their integer order.  That is exact only if the instructions do not
+    flush subnormals: all 256³ byte triples, on the device, against integer min / max."""
+    ctx = gpu.Context(0)
+    assert ctx.debug_pk_minmax3_f16() == 0
+    ctx.close()
+
+
 def test_synthetic_fill_matches_oracle(gpu, oracle_c):
     ctx = gpu.Context(0)
     ctx.set_grid(3, 2, 37, 11)

@@ -1,6 +1,8 @@
 """Launch the focus-map estimate + filter a few times (for rocprofv3 runs).  usage: python tools/run_focus.py [variant] [cols W H] [scene]"""
 import sys
 sys.path.insert(0, ".")
+sys.path.insert(0, "tools")
+import _ablib  # noqa: F401  (LFI_AB_LIB)
 import lfinterpolator_amd as L
 variant = sys.argv[1] if len(sys.argv) > 1 else "auto"
 cols = int(sys.argv[2]) if len(sys.argv) > 2 else 8
