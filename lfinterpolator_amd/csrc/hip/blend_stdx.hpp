@@ -1,0 +1,478 @@
+// blend_stdx.hpp — STD (the exact fp32 fmaf chain of Kernels::Standard::process, reference src/kernels.cu:292-342) for light fields of
+// MORE than 64 images (15×15 grids: four chunks of images) at matrix-core speed: the band method of blend_planar<STDF>, extended over
+// chunks.
+//
+// blend_planar<STDF> decides most bytes from the fp16-MFMA sum and recomputes the sums that land within a band around x.5 with the
+// chain itself — from the pixel bytes of ALL images of the tile, which must still be in LDS.  With 225 images a tile's stack is 86 KB:
+// it does not stay (round 2 therefore ran the exact-fp32 MFMA kernel on 15×15 grids: 6.9 ms at config 5, fp32-pipe-bound).
+// Here the chain's bytes come back a second time instead:
+//
+//   per tile, units  M(NCH−1) … M(1)   fp16 MFMA k-loops of blend_p3 over the chunks in DESCENDING order (the sum's order is free)
+//                    MC(0)             the last k-loop, on chunk 0; epilogue: band test on all sums, RGBA stores of the rounded bytes,
+//                                      the sums inside the band queued per wave (≤ 128; more take a slow path); the chain's first 64
+//                                      images for the queued sums — chunk 0 is the one buffer still resident
+//                    C(1) … C(NCH−1)   the same chunks fetched AGAIN through the same LDS-DMA ring (they left this workgroup's L2 /
+//                                      the Infinity Cache microseconds ago), chain continued in ascending image order; after the last
+//                                      one the chain's bytes are patched over the rounded ones (byte stores by the wave that wrote the
+//                                      dwords: same-wave stores to one address retire in order)
+//
+// so HBM sees the inputs once; the second fetch is cache traffic.  Pipeline (persistent workgroups, ring of three buffers two units
+// ahead, one barrier and one hand-counted vmcnt wait per unit), operand maps, DMA addressing: blend_p3.hpp, four waves of 16 views.
+//
+// The band.  acc = S̃·2^-9 is the MFMA estimate of the exact sum S (weights ×2^15, pixel bytes as fp16 subnormals).
+//   |S̃ − S| ≤ N·2^-17   accumulation error of the matrix pipe on sums below 512: MEASURED on gfx950 and asserted by
+//                        tests/test_gpu_parity.py::test_mfma_f16_accumulation_error_bound (LFI_FLAG_STD_ANALYTIC_BAND: N·2^-15, analytic);
+//   |s_N − S| ≤ N·½ulp(s_N)   the chain: N roundings to nearest of non-negative partial sums that only grow (weights and pixels are
+//                        non-negative, rounding is monotone), so every partial sum is ≤ s_N and every rounding error ≤ half an ulp of s_N.
+//                        The binade is taken from S̃ + (the widest band), which is ≥ s_N.  (blend_planar<STDF> budgets N·2^-16, half an
+//                        ulp below 512, for every sum; at S ≈ 127 this is four times narrower — the queue is what costs time here.)
+// A sum farther than the two together (+ 2^-12) from every half-integer rounds to the chain's byte; the others are recomputed.
+// Bit-exact against the oracle like every STD kernel (same tests).  Preconditions (host): weights finite, in [0, 2), every view's
+// weights sum to at most 2; the planar input copy.
+#pragma once
+
+#include "blend_p3.hpp"
+
+namespace lfi {
+
+constexpr int SX_QCAP = 128; // queued (pixel, view, channel) sums per wave and tile: two per lane
+
+template <int NCH>
+__host__ __device__ constexpr int sx_chunk_of(int u) // chunk of unit u of a tile: NCH−1 … 1, 0 (MC), 1 … NCH−1
+{
+    return u < NCH ? NCH - 1 - u : u - NCH + 1;
+}
+
+template <bool NT_STORE, int NCH>
+__global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const int tiles_x, const int n_tiles, const int reverse)
+{
+    static_assert(NCH >= 2 && NCH <= 4, "two to four chunks of 64 images");
+    constexpr int NW = 4, OPW = 2;
+    constexpr int NU = 2 * NCH - 1; // units per tile
+    constexpr int QUEUE_OFF = 3 * P3_BUF_B + LFI_MAX_IMAGES * 8;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[QUEUE_OFF + NW * SX_QCAP * 2];
+    static_assert(sizeof(lds) <= 81920, "two workgroups per CU");
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, kg = lane >> 4;
+    const int W = a.width, H = a.height;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr_t)lds)));
+    const size_t shift_stride = (size_t)a.in_rows * a.planar_pitch; // one byte plane of the planar inputs
+    int2 *off_table = reinterpret_cast<int2 *>(lds + 3 * P3_BUF_B);
+    for(int g = threadIdx.x; g < a.n_images; g += 64 * NW)
+    {
+        const lfi_int2 o = a.focused[g];
+        off_table[g] = make_int2(o.x, o.y);
+    }
+    uint16_t *queue = reinterpret_cast<uint16_t *>(lds + QUEUE_OFF) + wave * SX_QCAP;
+
+    // this wave's 16 views (v0 + 16·wave …): all their weights ×2^15 as MFMA A fragments (k-step s = images 32s … 32s+31); lane l holds
+    // view l&15, images 32s + 8(l>>4) + j — the chain reads them back through ds_bpermute
+    const int vw0 = a.v0 + 16 * wave;
+    half8 wreg[2 * NCH];
+#pragma unroll
+    for(int s = 0; s < 2 * NCH; s++)
+    {
+        const int k = 32 * s + 8 * kg;
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if(k < a.k_pad) // rows are k_pad halves long (a multiple of 16): nothing is read across a row's end
+            w = *reinterpret_cast<const u32x4 *>(a.w16s + (size_t)(vw0 + n) * a.k_pad + k);
+        wreg[s] = __builtin_bit_cast(half8, w);
+    }
+    // the compiler's wait for these loads belongs HERE, before any LDS-DMA is in flight (blend_p3.hpp)
+#pragma unroll
+    for(int s = 0; s < 2 * NCH; s++)
+        asm volatile("" : "+v"(wreg[s]));
+
+    const int G = gridDim.x;
+    const int t0 = int(xcd_contiguous(blockIdx.x, gridDim.x));
+    if(t0 >= n_tiles)
+        return;
+    __syncthreads(); // the offset table is complete
+
+    // ---- LDS-DMA of one unit: blend_p3's pieces (wave w moves octets w and w + 4 of every channel) ----------------------------------
+    struct Pieces
+    {
+        int ox[OPW], oy[OPW];
+        uint32_t img_off[OPW];
+        int g_base[OPW];
+    };
+    auto lookup = [&](const int chunk) {
+        Pieces pc;
+#pragma unroll
+        for(int o2 = 0; o2 < OPW; o2++)
+        {
+            const int octet = wave + NW * o2;
+            const int g_base = min(P3_KC * chunk + 8 * octet, a.n_images - 1);
+            const int dg = min(lane >> 3, a.n_images - 1 - g_base); // padded images (zero weights) re-read the last one
+            const int2 o = off_table[g_base + dg];
+            pc.ox[o2] = o.x;
+            pc.oy[o2] = o.y;
+            pc.img_off[o2] = uint32_t(dg) * 12u * uint32_t(shift_stride);
+            pc.g_base[o2] = g_base;
+        }
+        return pc;
+    };
+    auto tile_xy = [&](const int t_seq, int &ty, int &x0) {
+        const int t = reverse ? n_tiles - 1 - t_seq : t_seq;
+        ty = t / tiles_x; // row inside the output window
+        x0 = (t - ty * tiles_x) * P3_TPX;
+    };
+    auto issue = [&](const int t_seq, const int chunk, const int buf, const Pieces &pc) {
+        int ty, x0;
+        tile_xy(t_seq, ty, x0);
+        const int y = a.out_y0 + ty;
+        const int kc = min(P3_KC, a.k_pad - P3_KC * chunk);
+        const uint32_t dst = lds_base + uint32_t(buf) * P3_BUF_B;
+        int count = 0;
+#pragma unroll
+        for(int o2 = 0; o2 < OPW; o2++)
+        {
+            const int octet = wave + NW * o2;
+            if(8 * octet >= kc)
+                continue; // wave-uniform: the chunk is shorter (its length is a multiple of 16)
+            const int sy = clampi(y + pc.oy[o2], 0, H - 1) - a.in_y0;
+            const int start = x0 + pc.ox[o2] + a.planar_padx;
+            const int k = start & 3;
+            const uint32_t row_off = __umul24(__umul24(uint32_t(k), uint32_t(a.in_rows)) + uint32_t(sy), uint32_t(a.planar_pitch));
+            const uint32_t voff = pc.img_off[o2] + row_off + uint32_t(start - k) + 16u * uint32_t(lane & 7);
+            const uint8_t *sbase = a.planar + (size_t)__builtin_amdgcn_readfirstlane(pc.g_base[o2]) * 12 * shift_stride;
+#pragma unroll
+            for(int ch = 0; ch < 3; ch++)
+                dma16_s(sbase + (size_t)ch * 4 * shift_stride, voff, dst + uint32_t(ch * P3_CH_B + p3_octet_off(octet)));
+            count += 3;
+        }
+        return count;
+    };
+
+    // ---- the MFMA k-loop of one unit (blend_p3's, 16 views per wave) ----------------------------------------------------------------
+    f32x4 acc[8][3]; // [block = pixel 8n + blk][channel]: views 4kg + i, acc = S̃·2^-9
+    const uint32_t lane_px = uint32_t(1024 * kg + 128 * ((kg + 1) >> 1) + 8 * n); // p3_octet_off(kg) + this lane's 8 pixels
+    auto compute = [&](const half8 (&wk)[2], const int buf, const int kc, auto fresh_tag) {
+        constexpr bool fresh = decltype(fresh_tag)::value;
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const uint8_t *pb = lds + buf * P3_BUF_B + lane_px;
+        const int n_groups = kc > 32 ? 6 : 3;
+        u32x2 d[2][8];
+        auto load_group = [&](const int grp, u32x2 (&dst)[8]) {
+            const int ks = grp / 3, ch = grp - 3 * ks;
+#pragma unroll
+            for(int j = 0; j < 8; j++)
+                dst[j] = *reinterpret_cast<const u32x2 *>(pb + ch * P3_CH_B + p3_octet_off(4 * ks) + 128 * j);
+        };
+        load_group(0, d[0]);
+#pragma unroll
+        for(int grp = 0; grp < 6; grp++)
+        {
+            if(grp >= n_groups)
+                break;
+            if(grp + 1 < 6 && grp + 1 < n_groups)
+                load_group(grp + 1, d[(grp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ks = grp / 3, ch = grp - 3 * ks;
+            const u32x2(&dc)[8] = d[grp & 1];
+#pragma unroll
+            for(int b = 0; b < 8; b++)
+            {
+                u32x4 bf;
+#pragma unroll
+                for(int q = 0; q < 4; q++)
+                {
+                    const uint32_t lo = b < 4 ? dc[2 * q].x : dc[2 * q].y, hi = b < 4 ? dc[2 * q + 1].x : dc[2 * q + 1].y;
+                    bf[q] = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | uint32_t(b & 3) | (uint32_t(4 + (b & 3)) << 16));
+                }
+                acc[b][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[ks], __builtin_bit_cast(half8, bf), (ks == 0 && fresh) ? zero4 : acc[b][ch], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- band constants (file header) ------------------------------------------------------------------------------------------------
+    const float nf = float(a.n_images);
+    const float c0 = nf * ((a.flags & LFI_FLAG_STD_ANALYTIC_BAND) ? 0x1p-15f : 0x1p-17f) + 0x1p-12f; // accumulation error + margin, in units of S
+    const float bmax_acc = (c0 + nf * 0x1p-16f) * 0x1p-9f;  // the widest band (sums below 512), in units of acc
+    const float base_acc = (0.5f - c0) * 0x1p-9f;           // inside(acc) = base − N·2^-24·pow2(acc + bmax): |d| above it ⇒ recompute
+    const float chain_acc = nf * 0x1p-24f;
+
+    // ---- the chain over one chunk for this lane's queued sums, from buffer `buf` (images ascending: src/kernels.cu:328-338) ----------
+    // weights: the wave's A fragments, fetched across lanes (view v16's images 32ks + 8kq + j sit in lane v16 + 16kq, dword j/2)
+    struct Entry
+    {
+        uint32_t px, v16, ch; // pixel of the tile, view of the wave, channel
+        float s15;            // 2^15 · (the reference's running sum): a power-of-two scaling commutes with every rounding
+        bool have;
+    };
+    auto decode = [&](const uint32_t code, const bool have) {
+        Entry e;
+        const uint32_t src = code & 63u, bit = (code >> 6) & 31u, i = code >> 11;
+        const uint32_t b = (bit * 11u) >> 5; // bit / 3 for bit < 24
+        e.ch = bit - 3u * b;
+        e.px = 8u * (src & 15u) + b;
+        e.v16 = 4u * (src >> 4) + i;
+        e.s15 = 0.0f;
+        e.have = have;
+        return e;
+    };
+    auto chain = [&](auto cc_tag, const int buf, const int kc, Entry &e) {
+        constexpr int cc = decltype(cc_tag)::value;
+        const uint8_t *pb = lds + buf * P3_BUF_B + e.ch * P3_CH_B + e.px;
+        float s = e.s15;
+#pragma unroll
+        for(int ks = 0; ks < 2; ks++)
+        {
+            if(32 * ks >= kc) // wave-uniform
+                break;
+            const u32x4 wv = __builtin_bit_cast(u32x4, wreg[2 * cc + ks]);
+#pragma unroll
+            for(int kq = 0; kq < 4; kq++)
+            {
+                const int src_lane = int(e.v16) + 16 * kq;
+#pragma unroll
+                for(int jp = 0; jp < 4; jp++)
+                {
+                    const uint32_t w2 = uint32_t(__builtin_amdgcn_ds_bpermute(4 * src_lane, int(wv[jp])));
+#pragma unroll
+                    for(int h = 0; h < 2; h++)
+                    {
+                        const float w = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(h ? w2 >> 16 : w2)));
+                        const float p = static_cast<float>(pb[p3_octet_off(4 * ks + kq) + 128 * (2 * jp + h)]);
+                        s = __builtin_fmaf(p, w, s); // addWeighted, src/kernels.cu:292-299
+                    }
+                }
+            }
+        }
+        e.s15 = s;
+    };
+    // (unsigned char)__float2int_rn(sum) (uch4, src/kernels.cu:301-310): + 2^23 rounds to nearest-even and leaves the integer in the low bits
+    auto byte_of = [](const float s15) { return __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; };
+
+    // ---- the unit sequence of this workgroup: tiles t0, t0 + G, …; units 0 … NU−1 of each ---------------------------------------------
+    int it = t0, iu = 0; // issue cursor
+    auto advance_issue = [&] {
+        if(++iu == NU)
+        {
+            iu = 0;
+            it += G;
+        }
+    };
+    auto chunk_of_rt = [](const int u) { return u < NCH ? NCH - 1 - u : u - NCH + 1; };
+    Pieces pc = lookup(chunk_of_rt(0));
+    issue(it, chunk_of_rt(0), 0, pc);
+    advance_issue();
+    pc = lookup(chunk_of_rt(iu));
+    bool have1 = it < n_tiles;
+    int nd1 = 0;
+    if(have1)
+    {
+        nd1 = issue(it, chunk_of_rt(iu), 1, pc);
+        advance_issue();
+        pc = lookup(chunk_of_rt(iu));
+    }
+    int ct = t0, buf = 0;
+    int st1 = 0, st2 = 0;
+    const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw0, 16)); // ≤ 0: this wave only helps with the DMA
+    Entry e0 = decode(0u, false), e1 = decode(0u, false);
+    bool second_round = false; // more than 64 sums queued (wave-uniform)
+
+    auto unit = [&](auto u_tag) -> bool {
+        constexpr int u = decltype(u_tag)::value;
+        constexpr int cc = sx_chunk_of<NCH>(u);
+        constexpr bool is_m = u < NCH;       // an MFMA unit (the last of them, u == NCH − 1, is MC)
+        constexpr bool is_mc = u == NCH - 1;
+        constexpr bool is_last = u == NU - 1;
+        const int allowed = st2 + (have1 ? nd1 : 0) + st1;
+        switch(min(allowed, 63) >> 2)
+        {
+            case 15: LFI_P3_WAIT(60); break;
+            case 14: LFI_P3_WAIT(56); break;
+            case 13: LFI_P3_WAIT(52); break;
+            case 12: LFI_P3_WAIT(48); break;
+            case 11: LFI_P3_WAIT(44); break;
+            case 10: LFI_P3_WAIT(40); break;
+            case 9: LFI_P3_WAIT(36); break;
+            case 8: LFI_P3_WAIT(32); break;
+            case 7: LFI_P3_WAIT(28); break;
+            case 6: LFI_P3_WAIT(24); break;
+            case 5: LFI_P3_WAIT(20); break;
+            case 4: LFI_P3_WAIT(16); break;
+            case 3: LFI_P3_WAIT(12); break;
+            case 2: LFI_P3_WAIT(8); break;
+            case 1: LFI_P3_WAIT(4); break;
+            default: LFI_P3_WAIT(0); break;
+        }
+        __builtin_amdgcn_s_barrier(); // everybody's pieces of this unit have landed; everybody is done with the previous unit's buffer
+        asm volatile("" ::: "memory");
+        const bool have2 = have1 && it < n_tiles;
+        int nd2 = 0;
+        if(have2)
+        {
+            nd2 = issue(it, chunk_of_rt(iu), buf == 0 ? 2 : buf - 1, pc);
+            advance_issue();
+            pc = lookup(chunk_of_rt(iu));
+        }
+        const int kc = min(P3_KC, a.k_pad - P3_KC * cc);
+        st2 = st1;
+        st1 = 0;
+        if(nvalid > 0)
+        {
+            int ty, x0;
+            tile_xy(ct, ty, x0);
+            if constexpr(is_m)
+            {
+                half8 wk[2] = {wreg[2 * cc], wreg[2 * cc + 1]};
+                compute(wk, buf, kc, std::integral_constant<bool, u == 0>{}); // the first chunk of a tile starts from a zero C operand
+            }
+            if constexpr(is_mc)
+            {
+                // ---- epilogue: round every sum, store RGBA, find the sums inside the band -----------------------------------------------
+                uint32_t mask[4] = {0u, 0u, 0u, 0u}; // [i]: bit 3b + channel ↔ acc[b][channel][i] needs the chain
+                uint32_t px_ok = 0u;                 // the same 24 bits: pixel 8n + b inside the image
+#pragma unroll
+                for(int b = 0; b < 8; b++)
+                    px_ok |= (x0 + 8 * n + b < W) ? 7u << (3 * b) : 0u;
+                uint8_t *ubase = a.views + (((size_t)vw0 * a.out_rows + ty) * W + x0) * 4;
+                const size_t vstride = (size_t)a.out_rows * W * 4; // bytes between consecutive views
+                const bool full_x = x0 + 8 * n + 8 <= W;
+#pragma unroll
+                for(int i = 0; i < 4; i++)
+                {
+                    if(i >= nvalid) // wave-uniform; otherwise lane (n = 0, kg = 0) is active below
+                        continue;
+                    uint32_t rgba[8];
+#pragma unroll
+                    for(int b = 0; b < 8; b++)
+                    {
+                        uint32_t bits[3];
+#pragma unroll
+                        for(int ch = 0; ch < 3; ch++)
+                        {
+                            const float v = acc[b][ch][i];
+                            const float t = v + 16384.0f; // rounds S̃ to an integer (RN-even), left in the low mantissa bits
+                            const float dist = v - (t - 16384.0f);
+                            const float pow2 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v + bmax_acc) & 0x7f800000u);
+                            const float inside = __builtin_fmaf(-chain_acc, pow2, base_acc);
+                            mask[i] |= __builtin_fabsf(dist) > inside ? 1u << (3 * b + ch) : 0u;
+                            bits[ch] = __builtin_bit_cast(uint32_t, t);
+                        }
+                        const uint32_t rg = __builtin_amdgcn_perm(bits[1], bits[0], 0x0c0c0400u); // [R, G, 0, 0]
+                        rgba[b] = __builtin_amdgcn_perm(bits[2], rg, 0x0d040100u);               // [R, G, B, 0xff]
+                    }
+                    const bool view_ok = 4 * kg + i < nvalid;
+                    mask[i] &= view_ok ? px_ok : 0u;
+                    uint32_t *out = reinterpret_cast<uint32_t *>(ubase + (size_t)(4 * kg + i) * vstride) + 8 * n;
+                    if(full_x)
+                    {
+                        if(view_ok)
+                        {
+                            const u32x4 lo4 = {rgba[0], rgba[1], rgba[2], rgba[3]}, hi4 = {rgba[4], rgba[5], rgba[6], rgba[7]};
+                            if constexpr(NT_STORE)
+                            {
+                                __builtin_nontemporal_store(lo4, reinterpret_cast<u32x4_a4 *>(out));
+                                __builtin_nontemporal_store(hi4, reinterpret_cast<u32x4_a4 *>(out + 4));
+                            }
+                            else
+                            {
+                                *reinterpret_cast<u32x4_a4 *>(out) = lo4;
+                                *reinterpret_cast<u32x4_a4 *>(out + 4) = hi4;
+                            }
+                        }
+                    }
+                    else if(view_ok) // the ragged right edge of the image: pixel by pixel
+                    {
+#pragma unroll
+                        for(int b = 0; b < 8; b++)
+                            if(x0 + 8 * n + b < W)
+                                out[b] = rgba[b];
+                    }
+                    // counted for the vmcnt bookkeeping only where certainly issued (lane n = 0, kg = 0 takes the full-width branch);
+                    // an undercount only makes the next waits stricter
+                    if(x0 + 8 <= W)
+                        st1 += 2;
+                }
+                // ---- compact the flagged sums into the wave's queue; what does not fit is recomputed here and now, from global memory ----
+                int count = 0;
+                while(true)
+                {
+                    const uint32_t any_bits = mask[0] | mask[1] | mask[2] | mask[3];
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(any_bits != 0u);
+                    if(m == 0ull)
+                        break;
+                    const int i_sel = mask[0] ? 0 : (mask[1] ? 1 : (mask[2] ? 2 : 3));
+                    const uint32_t word = i_sel == 0 ? mask[0] : (i_sel == 1 ? mask[1] : (i_sel == 2 ? mask[2] : mask[3]));
+                    const int bit = any_bits ? __builtin_ctz(word) : 0;
+                    const uint32_t rest = word & (word - 1u);
+                    mask[0] = i_sel == 0 ? rest : mask[0];
+                    mask[1] = i_sel == 1 ? rest : mask[1];
+                    mask[2] = i_sel == 2 ? rest : mask[2];
+                    mask[3] = i_sel == 3 ? rest : mask[3];
+                    const int ahead = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+                    const int slot = count + ahead;
+                    const bool mine = any_bits != 0u;
+                    if(mine && slot < SX_QCAP)
+                        queue[slot] = static_cast<uint16_t>(uint32_t(lane) | (uint32_t(bit) << 6) | (uint32_t(i_sel) << 11));
+                    const bool spill = mine && slot >= SX_QCAP;
+                    if(__builtin_amdgcn_ballot_w64(spill) != 0ull) // wave-uniform; rare (adversarial inputs: every sum a tie)
+                    {
+                        // this lane's own sum, tap by tap from the planar copy (shift copy 0: pixel x at byte x + padx) and the weight table
+                        const uint32_t b = (uint32_t(bit) * 11u) >> 5, ch = uint32_t(bit) - 3u * b;
+                        const int x = x0 + 8 * n + int(b), y = a.out_y0 + ty;
+                        const int view = vw0 + 4 * kg + i_sel;
+                        float s = 0.0f;
+                        if(spill)
+                        {
+                            const uint16_t *wrow = a.w16s + (size_t)view * a.k_pad;
+                            for(int g = 0; g < a.n_images; g++)
+                            {
+                                const int2 o = off_table[g];
+                                const int sy = clampi(y + o.y, 0, H - 1) - a.in_y0;
+                                const uint8_t p = a.planar[((size_t)g * 3 + ch) * 4 * shift_stride + (size_t)sy * a.planar_pitch + (x + o.x + a.planar_padx)];
+                                const float w = static_cast<float>(__builtin_bit_cast(_Float16, wrow[g]));
+                                s = __builtin_fmaf(static_cast<float>(p), w, s);
+                            }
+                            (ubase + (size_t)(4 * kg + i_sel) * vstride)[(8 * n + int(b)) * 4 + int(ch)] = static_cast<uint8_t>(byte_of(s));
+                        }
+                    }
+                    count += __builtin_popcountll(m);
+                }
+                const int queued = min(count, SX_QCAP);
+                second_round = queued > 64;
+                const bool have0 = lane < queued, have1q = 64 + lane < queued;
+                const uint32_t code0 = queue[have0 ? lane : 0], code1 = queue[have1q ? 64 + lane : 0];
+                e0 = decode(have0 ? code0 : 0u, have0); // lanes without a sum run the chain on entry 0 and store nothing
+                e1 = decode(have1q ? code1 : 0u, have1q);
+            }
+            if constexpr(!is_m || is_mc)
+            {
+                chain(std::integral_constant<int, cc>{}, buf, kc, e0);
+                if(second_round)
+                    chain(std::integral_constant<int, cc>{}, buf, kc, e1);
+            }
+            if constexpr(is_last)
+            {
+                // the chain's bytes over the rounded ones (not counted in st1: an undercount is safe)
+                uint8_t *ubase = a.views + (((size_t)vw0 * a.out_rows + ty) * W + x0) * 4;
+                const size_t vstride = (size_t)a.out_rows * W * 4;
+                if(e0.have)
+                    (ubase + (size_t)e0.v16 * vstride)[e0.px * 4u + e0.ch] = static_cast<uint8_t>(byte_of(e0.s15));
+                if(second_round && e1.have)
+                    (ubase + (size_t)e1.v16 * vstride)[e1.px * 4u + e1.ch] = static_cast<uint8_t>(byte_of(e1.s15));
+            }
+        }
+        if(!have1)
+            return false;
+        if constexpr(is_last)
+            ct += G;
+        buf = buf == 2 ? 0 : buf + 1;
+        have1 = have2;
+        nd1 = nd2;
+        return true;
+    };
+    bool more = true;
+    while(more)
+        p3_for_each_chunk<NU>([&](auto u_tag) {
+            if(more)
+                more = unit(u_tag);
+        });
+}
+
+} // namespace lfi

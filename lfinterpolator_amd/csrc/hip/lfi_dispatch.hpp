@@ -10,6 +10,7 @@
 #include "blend_ten_persist.hpp"
 #include "blend_planar.hpp"
 #include "blend_p3.hpp"
+#include "blend_stdx.hpp"
 #include "blend_wave.hpp"
 
 namespace {
@@ -106,13 +107,38 @@ void launch_wave(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 
 // STD through blend_planar<STDF> (MFMA sum + exact recomputation inside the rounding band) when launch_blend has validated the
 // planar copy and the weights for it, else the exact-fp32 MFMA kernels
-void launch_std_filtered(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+void launch_std_filtered(const lfi_ctx *c, const KernelArgs &a_in, bool all_focus)
 {
-    if(!a.planar || all_focus || a.k_pad > 64)
+    if(!a_in.planar || all_focus || a_in.k_pad > 4 * lfi::P3_KC)
     {
-        launch_wave<true, 2, true>(c, a, all_focus);
+        launch_wave<true, 2, true>(c, a_in, all_focus);
         return;
     }
+    if(a_in.k_pad > 64)
+    {
+        // more than one chunk of images (15×15 grids): blend_stdx — the band method with the chain's bytes fetched a second time;
+        // one launch per 64 views (the accumulators of a wave hold 16 views)
+        const int tiles_x = (a_in.width + lfi::P3_TPX - 1) / lfi::P3_TPX;
+        const int n_tiles = tiles_x * a_in.out_rows;
+        const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+        const int nch = (a_in.k_pad + lfi::P3_KC - 1) / lfi::P3_KC;
+        const int reverse = next_sweep_direction(c);
+        note_kernel(c, "blend_stdx<STD>");
+        for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 64)
+        {
+            KernelArgs a = a_in;
+            a.v0 = v0;
+            a.v1 = std::min(v0 + 64, a_in.v1);
+            switch(nch)
+            {
+                case 2: hipLaunchKernelGGL((lfi::blend_stdx<true, 2>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse); break;
+                case 3: hipLaunchKernelGGL((lfi::blend_stdx<true, 3>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse); break;
+                default: hipLaunchKernelGGL((lfi::blend_stdx<true, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse); break;
+            }
+        }
+        return;
+    }
+    const KernelArgs &a = a_in;
     const int tiles_x = (a.width + 127) / 128;
     const int n_tiles = tiles_x * a.out_rows;
     const int passes = (a.v1 - a.v0 + 63) / 64;
@@ -267,8 +293,8 @@ bool wants_planar(const lfi_ctx *c, int method, int all_focus, const KernelArgs 
         return false;
     if(method == LFI_METHOD_TEN_WM)
         return kTenVariants[c->ten_variant].planar && !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH);
-    // STD: blend_planar<STDF> — one chunk, and weights for which its error bounds hold
-    return method == LFI_METHOD_STD && kStdVariants[c->std_variant].planar && c->weights_sum_ok && a.k_pad <= 64;
+    // STD: blend_planar<STDF> (one chunk of images) / blend_stdx (up to four) — weights for which their error bounds hold
+    return method == LFI_METHOD_STD && kStdVariants[c->std_variant].planar && c->weights_sum_ok && a.k_pad <= 4 * lfi::P3_KC;
 }
 
 // planar view layout: does blend_p3 serve this launch?  (TEN_WM, fixed focus, weights in [0, 2) for the packed epilogue, no

@@ -92,7 +92,7 @@ LLVM_BIN = "/opt/rocm/lib/llvm/bin"
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM_BIN, "llvm-readelf")), reason="ROCm LLVM tools not installed")
 def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_path):
-    """The LDS-DMA pipelines (blend_p3, blend_planar, blend_persist, blend_wave) wait with HAND-COUNTED `s_waitcnt vmcnt(n)`: n is the
+    """The LDS-DMA pipelines (blend_p3, blend_stdx, blend_planar, blend_persist, blend_wave) wait with HAND-COUNTED `s_waitcnt vmcnt(n)`: n is the
     number of vector-memory instructions the kernel itself issued after the DMA it waits for.  Anything the compiler adds to that
     queue behind our back breaks the count silently: register spills (scratch loads / stores are vector-memory operations), or an
     epilogue whose stores were merged or split.  So: none of these kernels may use scratch, and blend_p3's epilogues must consist of
@@ -108,7 +108,8 @@ def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_pat
             kernels[name] = {}
         elif name and ":" in line and line.split(":")[0] in (".private_segment_fixed_size", ".vgpr_spill_count", ".sgpr_spill_count", ".vgpr_count"):
             kernels[name][line.split(":")[0]] = int(line.split(":")[1])
-    pipelined = [k for k in kernels if any(s in k for s in ("blend_p3", "blend_planar", "blend_persist", "blend_wave"))]
+    pipelined = [k for k in kernels if any(s in k for s in ("blend_p3", "blend_planar", "blend_persist", "blend_wave", "blend_stdx"))]
+    assert sum("blend_stdx" in k for k in pipelined) == 3     # two, three and four chunks of images
     assert len(pipelined) >= 10, sorted(kernels)
     p3_name = re.compile(r"blend_p3ILb1ELi(\d)ELi(\d)ELi(\d)EEEv")  # <true, chunks, ablation, view groups per wave>
     n_two_groups = 0

@@ -535,6 +535,67 @@ def test_std_rounding_band_adversarial(kind, gpu, oracle_c):
     ctx.close()
 
 
+@pytest.mark.parametrize("cols,rows,W,H,V,kind", [
+    (9, 9, 200, 6, 64, "random"),            # two chunks of images (81 → k_pad 96: a short second chunk)
+    (12, 12, 131, 5, 37, "random"),          # three chunks; ragged width, a wave with five views, an idle wave
+    (15, 15, 300, 4, 64, "random"),          # four chunks (BASELINE configs 3 and 5)
+    (15, 15, 140, 3, 70, "random"),          # two launches of views (64 + 6)
+    (13, 10, 257, 3, 64, "ties_everywhere"), # every sum an exact tie: the queue overflows, the spill path computes from global memory
+    (15, 15, 128, 3, 16, "flat_images"),
+    (11, 11, 260, 4, 48, "sum_1p999"),       # sums up to 510: the top binade of the band
+    (15, 15, 200, 3, 33, "tiny_weights"),
+])
+def test_std_band_method_over_several_chunks(cols, rows, W, H, V, kind, gpu, oracle_c):
+    """STD on grids of more than 64 images goes through blend_stdx: fp16-MFMA sums over all chunks, the sums inside the rounding band
+    recomputed with the chain from a second fetch of the tile's chunks.  Bit-exact against the oracle on random inputs and on inputs
+    built to sit on the band; the exact-fp32 MFMA kernel and the analytic band agree."""
+    n = cols * rows
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.1, 0.0, 3.0, 1.783, V)
+    rng = np.random.default_rng(n + V)
+    lf = oracle_c.synthetic_lf(n, W, H, 9 + n)
+    if kind != "random":
+        w = np.zeros((V, n), np.float32)
+        if kind == "ties_everywhere":
+            for v in range(V):
+                a, b = rng.choice(n, 2, replace=False)
+                w[v, a] = w[v, b] = 0.5
+            lf[..., :3] = (lf[..., :3] // 2) * 2
+            lf[::2, :, :, :3] += 1
+        elif kind == "flat_images":
+            w = np.abs(rng.standard_normal((V, n))).astype(np.float32)
+            w /= w.sum(1, keepdims=True)
+            lf[..., :3] = rng.integers(0, 256, (n, 1, 1, 3), dtype=np.uint8)
+        elif kind == "sum_1p999":
+            w = np.abs(rng.standard_normal((V, n))).astype(np.float32)
+            w *= 1.99 / w.sum(1, keepdims=True)
+        else:
+            w = (rng.random((V, n)) * 3e-5).astype(np.float32)
+            w[:, n // 2] = 0.75
+        hp.weights = _f16_bits(w)
+    lf[..., 3] = 255
+    want = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, threads=8)
+    for flags in (0, gpu.LFI_FLAG_STD_ANALYTIC_BAND, gpu.LFI_FLAG_SINGLE_SWEEP_DIRECTION):
+        ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf, flags=flags)
+        ctx.render("STD")
+        ctx.sync()
+        assert ctx.last_kernel_name() == "blend_stdx<STD>"
+        got = ctx.download_views()
+        assert (got == want).all(), (kind, flags, int((got != want).sum()))
+        if flags == 0:
+            ctx.render("STD")          # the second launch walks the image in the other direction
+            ctx.sync()
+            assert (ctx.download_views() == want).all(), (kind, "reverse sweep")
+            v0, v1 = V // 3, V // 3 + min(20, V - V // 3)
+            ctx.render("STD", v0=v0, v1=v1)
+            ctx.sync()
+            assert (ctx.download_views(v0, v1) == want[v0:v1]).all(), (kind, "view range")
+            ctx.set_output_layout("planar")      # RGBA scratch + conversion
+            ctx.render("STD")
+            ctx.sync()
+            assert (ctx.download_views() == want).all(), (kind, "planar layout")
+        ctx.close()
+
+
 def test_std_analytic_band_flag(gpu, oracle_c):
     """LFI_FLAG_STD_ANALYTIC_BAND sizes the band of blend_planar<STDF> with the analytic accumulation bound (a whole ulp per addend)
     instead of the measured one: same kernel, same bytes, more sums recomputed — bit-exact like the default."""
