@@ -172,7 +172,7 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         out["config3"] = entry(c3, ms, 45, ctx.last_kernel_name())
         ctx.set_output_layout("rgba")
         ms = timed(ctx, lambda: ctx.render("STD"), max(2, iters // 2))
-        out["config3_std"] = entry(c3, ms, 45, ctx.last_kernel_name(), "bit-exact STD on a 15x15 grid (four chunks of images)", flops_bound=True)
+        out["config3_std"] = entry(c3, ms, 45, ctx.last_kernel_name(), "bit-exact STD on a 15x15 grid (four chunks of images): fp16 MFMA sums + the exact chain inside the rounding band")
         ctx.close()
 
     guarded(config3)
@@ -211,7 +211,7 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         # BASELINE config 5's comparison, fixed focus: bit-exact STD by the default kernel and by the NON-TENSOR wavefront kernel
         # (blend_std_vfma, the analogue of Standard::process, src/kernels.cu:312-342)
         ms = timed(ctx, lambda: ctx.render("STD"), max(2, iters // 4), warm=1)
-        out["config5_fixed_focus_std"] = entry(c5, ms, 64, ctx.last_kernel_name(), "bit-exact STD, default kernel", flops_bound=True)
+        out["config5_fixed_focus_std"] = entry(c5, ms, 64, ctx.last_kernel_name(), "bit-exact STD, default kernel")
         ctx.set_variant("STD", "vfma")
         ms = timed(ctx, lambda: ctx.render("STD"), 2, warm=1, rounds=2)
         out["config5_fixed_focus_std_nontensor"] = entry(c5, ms, 64, ctx.last_kernel_name(), "the non-tensor wavefront kernel (v_pk_fma_f32 chains)", flops_bound=True)

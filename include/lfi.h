@@ -217,7 +217,7 @@ int lfi_prepare(lfi_ctx *ctx, int method, int all_focus, int v0, int v1);
  * built it; 0 otherwise) — the capacity side of the planar-copy trade, reported by bench.py */
 typedef struct lfi_memory {
     size_t grid_bytes;      /* input planes (RGBA) */
-    size_t derived_bytes;   /* planar copy of the inputs: 12 bytes per pixel and image (+ padding) */
+    size_t derived_bytes;   /* planar copy of the inputs: 3 bytes per pixel and image (+ padding) */
     size_t views_bytes;     /* output planes */
     size_t maps_bytes;      /* focus maps */
     size_t workspace_bytes; /* focus-map workspace */

@@ -1,5 +1,5 @@
 // blend_p3.hpp — TEN_WM with three bytes per pixel on BOTH sides of the kernel: the planar, alpha-free copy of the inputs
-// (blend_planar.hpp) is read, and the views are written as alpha-free byte planes [view][R,G,B][rows][pitch].
+// (blend_planar.hpp: one byte plane per image and channel) is read, and the views are written as alpha-free byte planes [view][R,G,B][rows][pitch].
 //
 // Why: the blend is HBM-bound and the memory system gives this access pattern ≈4.8–5 TB/s whatever the kernel does
 // (tools/ablate_out.hip: the same gather with no arithmetic, 929 MB moved: 188–197 µs with RGBA views, 796 MB: 160–165 µs with
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
     struct Pieces
     {
         int ox[OPW], oy[OPW];
-        uint32_t img_off[OPW]; // (this lane's image − the octet's first image) · 12 planes, in bytes (< 2^32: checked on the host)
+        uint32_t img_off[OPW]; // (this lane's image − the octet's first image) · 3 planes, in bytes (< 2^32: checked on the host)
         int g_base[OPW];       // the octet's first image (wave-uniform), clamped to the last image
     };
     auto lookup = [&](const int chunk) {
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
             const int2 o = off_table[g_base + dg];
             pc.ox[o2] = o.x;
             pc.oy[o2] = o.y;
-            pc.img_off[o2] = uint32_t(dg) * 12u * uint32_t(shift_stride);
+            pc.img_off[o2] = uint32_t(dg) * 3u * uint32_t(shift_stride);
             pc.g_base[o2] = g_base;
         }
         return pc;
@@ -167,19 +167,17 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
             const int octet = wave + NW * o2;
             if(8 * octet >= kc)
                 continue; // wave-uniform: the chunk is shorter (its length is a multiple of 16)
-            // the run starts at pixel x0 + ox: dword aligned in shift copy (x0 + ox + padx) & 3; the padding exceeds every offset
+            // the run starts at pixel x0 + ox; the padding exceeds every offset
             const int sy = clampi(y + pc.oy[o2], 0, H - 1) - a.in_y0; // clamp in the full image, then index the held rows
-            const int start = x0 + pc.ox[o2] + a.planar_padx;
-            const int k = start & 3;
-            // (k·rows + sy)·pitch with full-rate 24-bit multiplies (rows, pitch < 2^24; the product < 2^32: checked on the host)
-            const uint32_t row_off = __umul24(__umul24(uint32_t(k), uint32_t(a.in_rows)) + uint32_t(sy), uint32_t(a.planar_pitch));
-            const uint32_t voff = pc.img_off[o2] + row_off + uint32_t(start - k) + 16u * uint32_t(lane & 7);
-            const uint8_t *sbase = a.planar + (size_t)__builtin_amdgcn_readfirstlane(pc.g_base[o2]) * 12 * shift_stride;
+            const int start = x0 + pc.ox[o2] + a.planar_padx; // any byte of the plane row (byte-aligned LDS-DMA: blend_planar.hpp)
+            // sy·pitch with a full-rate 24-bit multiply (rows, pitch < 2^24; an octet's 24 planes < 2^32 bytes: checked on the host)
+            const uint32_t voff = pc.img_off[o2] + __umul24(uint32_t(sy), uint32_t(a.planar_pitch)) + uint32_t(start) + 16u * uint32_t(lane & 7);
+            const uint8_t *sbase = a.planar + (size_t)__builtin_amdgcn_readfirstlane(pc.g_base[o2]) * 3 * shift_stride;
             if constexpr(ABL != 2)
             {
 #pragma unroll
                 for(int ch = 0; ch < 3; ch++)
-                    dma16_s(sbase + (size_t)ch * 4 * shift_stride, voff, dst + uint32_t(ch * P3_CH_B + p3_octet_off(octet)));
+                    dma16_s(sbase + (size_t)ch * shift_stride, voff, dst + uint32_t(ch * P3_CH_B + p3_octet_off(octet)));
                 count += 3;
             }
             else

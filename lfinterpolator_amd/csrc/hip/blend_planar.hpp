@@ -2,15 +2,17 @@
 //
 // blend_persist / blend_wave move 4·W·H·(N + V) bytes per launch and sit within ≈10 % of what the memory system gives that
 // pattern (profiles/r01_notes.md §3).  A quarter of the bytes READ is the alpha channel, which neither method uses
-// (reference src/kernels.cu:292-299, 353-370 read .x .y .z only).  An RGB-interleaved layout cannot be fetched by LDS-DMA at
-// arbitrary pixel shifts (sources must be dword aligned), a planar one can if every (image, channel) plane is kept in four
-// copies shifted by 0…3 bytes: a run that starts at pixel x0 is then a dword-aligned run of copy (x0 + pad) mod 4.  The copies
-// are padded left and right by more than the largest offset with replicated edge pixels, so clamp-to-edge in x
-// (cudaBoundaryModeClamp, src/kernels.cu:125) needs no per-pixel path at all; in y the row index is clamped per image.
+// (reference src/kernels.cu:292-299, 353-370 read .x .y .z only).  The derived copy keeps every (image, channel) as ONE byte plane,
+// padded left and right by more than the largest offset with replicated edge pixels, so clamp-to-edge in x
+// (cudaBoundaryModeClamp, src/kernels.cu:125) needs no per-pixel path at all; in y the row index is clamped per image.  A tile's
+// 128-pixel run of an image starts at an arbitrary BYTE of its plane row; LDS-DMA fetches it from there (round 3,
+// tools/probe_ldsdma_bytes.hip: byte-aligned sources are legal, land lane-linear and cost what a dword-aligned run that straddles
+// two cache lines costs — which every shifted run does; rounds 1–2 assumed dword alignment and kept FOUR byte-shifted copies of
+// every plane, 12 B per pixel·image instead of 3).
 // The memory system gives this pattern (192 byte-plane streams instead of 64 RGBA-plane streams) the full saving: gather +
 // scatter with no arithmetic 164–167 µs instead of 183–185 µs at config 2 (tools/ablate.hip, "planar").
 //
-// planar_build — once per change of the inputs (the context tracks them, include/lfi.h lfi_grid_modified): 12 byte planes per
+// planar_build — once per change of the inputs (the context tracks them, include/lfi.h lfi_grid_modified): 3 byte planes per
 //                image from its RGBA plane.
 // blend_planar — the workgroup pipeline of blend_persist (fixed focus; any number of images and views; row windows): 24 LDS-DMA
 //                pieces of 8 runs × 128 bytes per unit, 6 per wave (a run per wave-sized tile would be 32 bytes: four times the
@@ -33,7 +35,7 @@
 
 namespace lfi {
 
-// grid (ceil(pitch/1024), H, N): a thread writes one dword (4 consecutive bytes) of all 12 planes of its image row
+// grid (ceil(pitch/1024), H, N): a thread writes one dword (4 consecutive bytes) of the 3 planes of its image row
 // H = rows HELD per plane (the whole image, or the input rows of a row window)
 __global__ void __launch_bounds__(256) planar_build(const uint8_t *__restrict__ grid, uint8_t *__restrict__ planar, const int W, const int H,
                                                     const int pitch, const int padx)
@@ -43,23 +45,18 @@ __global__ void __launch_bounds__(256) planar_build(const uint8_t *__restrict__ 
         return;
     const int y = blockIdx.y, g = blockIdx.z;
     const uint32_t *row = reinterpret_cast<const uint32_t *>(grid) + ((size_t)g * H + y) * W;
-    // bytes j4 … j4+3 of shift copy k hold pixels j4 + k − padx … : seven consecutive pixels cover the four copies
-    uint32_t px[7];
+    uint32_t px[4]; // byte j of a plane row holds pixel j − padx, edges replicated
 #pragma unroll
-    for(int i = 0; i < 7; i++)
+    for(int i = 0; i < 4; i++)
         px[i] = row[clampi(j4 - padx + i, 0, W - 1)];
 #pragma unroll
     for(int c = 0; c < 3; c++)
-#pragma unroll
-        for(int k = 0; k < 4; k++)
-        {
-            uint32_t v = 0;
-#pragma unroll
-            for(int b = 0; b < 4; b++)
-                v |= ((px[k + b] >> (8 * c)) & 0xffu) << (8 * b);
-            uint8_t *plane = planar + ((((size_t)g * 3 + c) * 4 + k) * H + y) * pitch;
-            *reinterpret_cast<uint32_t *>(plane + j4) = v;
-        }
+    {
+        const uint32_t lo = __builtin_amdgcn_perm(px[1], px[0], 0x0c0c0400u + 0x0101u * uint32_t(c)); // [p0.c, p1.c, 0, 0]
+        const uint32_t hi = __builtin_amdgcn_perm(px[3], px[2], 0x0c0c0400u + 0x0101u * uint32_t(c));
+        uint8_t *plane = planar + (((size_t)g * 3 + c) * H + y) * pitch;
+        *reinterpret_cast<uint32_t *>(plane + j4) = lo | (hi << 16);
+    }
 }
 
 // STDF epilogue of one wave's 32 pixels × (MT·32 views from vbase): acc holds S·2^-9 (fp16 MFMA of pixel subnormals and ×2^15
@@ -276,7 +273,7 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
             const int2 o = off_table[g];
             pc.ox[j] = o.x;
             pc.oy[j] = o.y;
-            pc.plane0[j] = ((size_t)g * 3 + c) * 4 * shift_stride;
+            pc.plane0[j] = ((size_t)g * 3 + c) * shift_stride;
         }
         return pc;
     };
@@ -295,11 +292,11 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
             const int p = wave + 4 * j;
             if(8 * (p & 7) >= kc)
                 continue; // wave-uniform: the chunk is shorter (its length is a multiple of 16)
-            // the run starts at pixel x0 + ox: dword aligned in shift copy (x0 + ox + padx) & 3; the padding exceeds every offset
+            // the run starts at pixel x0 + ox = byte x0 + ox + padx of the plane row, ANY byte (LDS-DMA sources need no alignment:
+            // tools/probe_ldsdma_bytes.hip); the padding exceeds every offset
             const int sy = clampi(y + pc.oy[j], 0, H - 1) - a.in_y0; // clamp in the full image, then index the held rows
             const int start = x0 + pc.ox[j] + a.planar_padx;
-            const int k = start & 3;
-            dma16(a.planar + pc.plane0[j] + ((size_t)k * a.in_rows + sy) * a.planar_pitch + (start - k) + 16 * (lane & 7), dst + uint32_t(p) * 1024u);
+            dma16(a.planar + pc.plane0[j] + (size_t)sy * a.planar_pitch + start + 16 * (lane & 7), dst + uint32_t(p) * 1024u);
         }
     };
 

@@ -14,7 +14,8 @@
 //                    C(1) … C(NCH−1)   the same chunks fetched AGAIN through the same LDS-DMA ring (they left this workgroup's L2 /
 //                                      the Infinity Cache microseconds ago), chain continued in ascending image order; after the last
 //                                      one the chain's bytes are patched over the rounded ones (byte stores by the wave that wrote the
-//                                      dwords: same-wave stores to one address retire in order)
+//                                      dwords: same-wave stores to one address retire in order).  The C units of a tile run
+//                                      INTERLEAVED with the M units of the next tile (see the unit sequence below).
 //
 // so HBM sees the inputs once; the second fetch is cache traffic.  Pipeline (persistent workgroups, ring of three buffers two units
 // ahead, one barrier and one hand-counted vmcnt wait per unit), operand maps, DMA addressing: blend_p3.hpp, four waves of 16 views.
@@ -36,19 +37,18 @@
 namespace lfi {
 
 constexpr int SX_QCAP = 128; // queued (pixel, view, channel) sums per wave and tile: two per lane
+// measurement builds only (hipcc -DLFI_SX_ABL=n, tools/stdx_ablate.sh): 1 = no chain arithmetic (the C units still fetch), 2 = no C units at
+// all, 3 = 2 and no band test (plain rounding).  Outputs of n != 0 are wrong by construction.
+#ifndef LFI_SX_ABL
+#define LFI_SX_ABL 0
+#endif
 
-template <int NCH>
-__host__ __device__ constexpr int sx_chunk_of(int u) // chunk of unit u of a tile: NCH−1 … 1, 0 (MC), 1 … NCH−1
-{
-    return u < NCH ? NCH - 1 - u : u - NCH + 1;
-}
-
-template <bool NT_STORE, int NCH>
+template <bool NT_STORE, int NCH, bool ILV = false>
 __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const int tiles_x, const int n_tiles, const int reverse)
 {
     static_assert(NCH >= 2 && NCH <= 4, "two to four chunks of 64 images");
     constexpr int NW = 4, OPW = 2;
-    constexpr int NU = 2 * NCH - 1; // units per tile
+    constexpr int NU = 2 * NCH - 1; // unit slots per iteration
     constexpr int QUEUE_OFF = 3 * P3_BUF_B + LFI_MAX_IMAGES * 8;
     __shared__ __attribute__((aligned(16))) uint8_t lds[QUEUE_OFF + NW * SX_QCAP * 2];
     static_assert(sizeof(lds) <= 81920, "two workgroups per CU");
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
             const int2 o = off_table[g_base + dg];
             pc.ox[o2] = o.x;
             pc.oy[o2] = o.y;
-            pc.img_off[o2] = uint32_t(dg) * 12u * uint32_t(shift_stride);
+            pc.img_off[o2] = uint32_t(dg) * 3u * uint32_t(shift_stride);
             pc.g_base[o2] = g_base;
         }
         return pc;
@@ -133,14 +133,13 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
             if(8 * octet >= kc)
                 continue; // wave-uniform: the chunk is shorter (its length is a multiple of 16)
             const int sy = clampi(y + pc.oy[o2], 0, H - 1) - a.in_y0;
-            const int start = x0 + pc.ox[o2] + a.planar_padx;
-            const int k = start & 3;
-            const uint32_t row_off = __umul24(__umul24(uint32_t(k), uint32_t(a.in_rows)) + uint32_t(sy), uint32_t(a.planar_pitch));
-            const uint32_t voff = pc.img_off[o2] + row_off + uint32_t(start - k) + 16u * uint32_t(lane & 7);
-            const uint8_t *sbase = a.planar + (size_t)__builtin_amdgcn_readfirstlane(pc.g_base[o2]) * 12 * shift_stride;
+            const int start = x0 + pc.ox[o2] + a.planar_padx; // any byte of the plane row (byte-aligned LDS-DMA: blend_planar.hpp)
+            // sy·pitch with a full-rate 24-bit multiply (rows, pitch < 2^24; an octet's 24 planes < 2^32 bytes: checked on the host)
+            const uint32_t voff = pc.img_off[o2] + __umul24(uint32_t(sy), uint32_t(a.planar_pitch)) + uint32_t(start) + 16u * uint32_t(lane & 7);
+            const uint8_t *sbase = a.planar + (size_t)__builtin_amdgcn_readfirstlane(pc.g_base[o2]) * 3 * shift_stride;
 #pragma unroll
             for(int ch = 0; ch < 3; ch++)
-                dma16_s(sbase + (size_t)ch * 4 * shift_stride, voff, dst + uint32_t(ch * P3_CH_B + p3_octet_off(octet)));
+                dma16_s(sbase + (size_t)ch * shift_stride, voff, dst + uint32_t(ch * P3_CH_B + p3_octet_off(octet)));
             count += 3;
         }
         return count;
@@ -195,91 +194,106 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
     const float chain_acc = nf * 0x1p-24f;
 
     // ---- the chain over one chunk for this lane's queued sums, from buffer `buf` (images ascending: src/kernels.cu:328-338) ----------
-    // weights: the wave's A fragments, fetched across lanes (view v16's images 32ks + 8kq + j sit in lane v16 + 16kq, dword j/2)
-    struct Entry
-    {
-        uint32_t px, v16, ch; // pixel of the tile, view of the wave, channel
-        float s15;            // 2^15 · (the reference's running sum): a power-of-two scaling commutes with every rounding
-        bool have;
-    };
-    auto decode = [&](const uint32_t code, const bool have) {
-        Entry e;
+    // A queued sum = (pixel of the tile, view of the wave, channel) packed as px | v16 << 7 | ch << 11, and its running value s15 =
+    // 2^15 · (the reference's running sum): a power-of-two scaling commutes with every rounding.
+    // weights: the wave's A fragments, fetched across lanes (view v16's images 32ks + 8kq + j sit in lane v16 + 16kq, dword j/2).
+    // All LDS traffic of a k-step — 32 pixel bytes, 16 weight pairs — is issued BEFORE its first fma (staging registers + a scheduling
+    // barrier): written as read → convert → fma per image the compiler emitted exactly that, one LDS latency per image (0.6 ms of
+    // a 2.9 ms config-5 launch, tools/stdx_ablate.sh).
+    auto pack_entry = [](const uint32_t code) { // queue code (lane | bit << 6 | i << 11) → px | v16 << 7 | ch << 11
         const uint32_t src = code & 63u, bit = (code >> 6) & 31u, i = code >> 11;
         const uint32_t b = (bit * 11u) >> 5; // bit / 3 for bit < 24
-        e.ch = bit - 3u * b;
-        e.px = 8u * (src & 15u) + b;
-        e.v16 = 4u * (src >> 4) + i;
-        e.s15 = 0.0f;
-        e.have = have;
-        return e;
+        return (8u * (src & 15u) + b) | ((4u * (src >> 4) + i) << 7) | ((bit - 3u * b) << 11);
     };
-    auto chain = [&](auto cc_tag, const int buf, const int kc, Entry &e) {
+    auto chain = [&](auto cc_tag, const int buf, const int kc, const uint32_t entry, float &s15) {
         constexpr int cc = decltype(cc_tag)::value;
-        const uint8_t *pb = lds + buf * P3_BUF_B + e.ch * P3_CH_B + e.px;
-        float s = e.s15;
+        const uint32_t px = entry & 127u, v16 = (entry >> 7) & 15u, ch = entry >> 11;
+        const uint8_t *pb = lds + buf * P3_BUF_B + ch * P3_CH_B + px;
+        float s = s15;
 #pragma unroll
         for(int ks = 0; ks < 2; ks++)
         {
-            if(32 * ks >= kc) // wave-uniform
+            if(32 * ks >= kc) // wave-uniform: a chunk of ≤ 32 images has one k-step
                 break;
+            uint32_t w2[16], pbyte[32]; // staged per k-step (48 registers: a whole chunk's 96 spilled in the MC unit)
             const u32x4 wv = __builtin_bit_cast(u32x4, wreg[2 * cc + ks]);
 #pragma unroll
             for(int kq = 0; kq < 4; kq++)
             {
-                const int src_lane = int(e.v16) + 16 * kq;
+                const int src_lane = int(v16) + 16 * kq;
 #pragma unroll
                 for(int jp = 0; jp < 4; jp++)
-                {
-                    const uint32_t w2 = uint32_t(__builtin_amdgcn_ds_bpermute(4 * src_lane, int(wv[jp])));
+                    w2[4 * kq + jp] = uint32_t(__builtin_amdgcn_ds_bpermute(4 * src_lane, int(wv[jp])));
 #pragma unroll
-                    for(int h = 0; h < 2; h++)
-                    {
-                        const float w = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(h ? w2 >> 16 : w2)));
-                        const float p = static_cast<float>(pb[p3_octet_off(4 * ks + kq) + 128 * (2 * jp + h)]);
-                        s = __builtin_fmaf(p, w, s); // addWeighted, src/kernels.cu:292-299
-                    }
-                }
+                for(int j = 0; j < 8; j++)
+                    pbyte[8 * kq + j] = pb[p3_octet_off(4 * ks + kq) + 128 * j];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for(int kk = 0; kk < 32; kk++) // image 64·cc + 32·ks + kk, ascending
+            {
+                const uint32_t pair = w2[kk >> 1];
+                const float w = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(kk & 1 ? pair >> 16 : pair)));
+                s = __builtin_fmaf(static_cast<float>(pbyte[kk]), w, s); // addWeighted, src/kernels.cu:292-299
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        e.s15 = s;
+        s15 = s;
     };
     // (unsigned char)__float2int_rn(sum) (uch4, src/kernels.cu:301-310): + 2^23 rounds to nearest-even and leaves the integer in the low bits
     auto byte_of = [](const float s15) { return __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; };
 
-    // ---- the unit sequence of this workgroup: tiles t0, t0 + G, …; units 0 … NU−1 of each ---------------------------------------------
-    int it = t0, iu = 0; // issue cursor
+    // ---- the unit sequence of this workgroup ---------------------------------------------------------------------------------------
+    // Tiles t0, t0 + G, … (T of them).  Iteration j runs the MFMA units of tile j INTERLEAVED with the chain units of tile j − 1:
+    //      slot 0: M(NCH−1)   1: C'(1)   2: M(NCH−2)   3: C'(2)   …   2(NCH−2): M(1)   2NCH−3: C'(NCH−1)   2NCH−2: MC(0)
+    // (C' = a C unit of the previous tile; iteration 0 has no C' units, iteration T only C' units).  A C unit computes for a microsecond;
+    // three of them in a row left the fetches issued during them — the next tile's first chunks, from HBM — two short units of lead
+    // (0.4–0.6 ms of a config-5 launch, tools/stdx_ablate.sh).  Alternating, every fetch has an MFMA unit's time to land.
+    // ILV = false: the C units follow their own tile's MC unit (slots 0 … NCH−2: M, NCH−1: MC, NCH … 2NCH−2: C(1) … C(NCH−1)).
+    const int T = (n_tiles - 1 - t0) / G + 1;
+    auto slot_is_c = [](const int sl) { return ILV ? (sl & 1) != 0 : sl >= NCH; };
+    auto slot_valid = [&](const int j, const int sl) { return slot_is_c(sl) ? (LFI_SX_ABL < 2 && (ILV ? j >= 1 : j < T)) : j < T; };
+    auto slot_chunk = [](const int sl) { return ILV ? ((sl & 1) ? (sl + 1) / 2 : NCH - 1 - sl / 2) : (sl < NCH ? NCH - 1 - sl : sl - NCH + 1); };
+    auto slot_tile = [&](const int j, const int sl) { return t0 + ((ILV && slot_is_c(sl)) ? j - 1 : j) * G; };
+    int ij = 0, isl = 0; // issue cursor: the next unit to fetch; past the end when ij > T
     auto advance_issue = [&] {
-        if(++iu == NU)
+        do
         {
-            iu = 0;
-            it += G;
-        }
+            if(++isl == NU)
+            {
+                isl = 0;
+                ij++;
+            }
+        } while(ij <= T && !slot_valid(ij, isl));
     };
-    auto chunk_of_rt = [](const int u) { return u < NCH ? NCH - 1 - u : u - NCH + 1; };
-    Pieces pc = lookup(chunk_of_rt(0));
-    issue(it, chunk_of_rt(0), 0, pc);
+    auto issue_cursor = [&](const int buf, const Pieces &pc) { return issue(slot_tile(ij, isl), slot_chunk(isl), buf, pc); };
+    Pieces pc = lookup(slot_chunk(0));
+    issue_cursor(0, pc);
     advance_issue();
-    pc = lookup(chunk_of_rt(iu));
-    bool have1 = it < n_tiles;
+    bool have1 = ij <= T; // a unit after the current one exists (and is in flight)
     int nd1 = 0;
     if(have1)
     {
-        nd1 = issue(it, chunk_of_rt(iu), 1, pc);
+        pc = lookup(slot_chunk(isl));
+        nd1 = issue_cursor(1, pc);
         advance_issue();
-        pc = lookup(chunk_of_rt(iu));
     }
-    int ct = t0, buf = 0;
+    if(ij <= T)
+        pc = lookup(slot_chunk(isl));
+    int cj = 0, buf = 0; // compute cursor: iteration (the slot is the compile-time argument of `unit`)
     int st1 = 0, st2 = 0;
     const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw0, 16)); // ≤ 0: this wave only helps with the DMA
-    Entry e0 = decode(0u, false), e1 = decode(0u, false);
-    bool second_round = false; // more than 64 sums queued (wave-uniform)
+    // the queued sums of the tile whose MC unit ran last: two per lane
+    uint32_t entry0 = 0u, entry1 = 0u;
+    float s0 = 0.0f, s1 = 0.0f;
+    int queued = 0; // wave-uniform
 
-    auto unit = [&](auto u_tag) -> bool {
-        constexpr int u = decltype(u_tag)::value;
-        constexpr int cc = sx_chunk_of<NCH>(u);
-        constexpr bool is_m = u < NCH;       // an MFMA unit (the last of them, u == NCH − 1, is MC)
-        constexpr bool is_mc = u == NCH - 1;
-        constexpr bool is_last = u == NU - 1;
+    auto unit = [&](auto sl_tag) -> bool {
+        constexpr int sl = decltype(sl_tag)::value;
+        constexpr bool is_c = ILV ? (sl & 1) != 0 : sl >= NCH;
+        constexpr bool is_mc = ILV ? sl == NU - 1 : sl == NCH - 1;
+        constexpr int cc = ILV ? (is_c ? (sl + 1) / 2 : NCH - 1 - sl / 2) : (sl < NCH ? NCH - 1 - sl : sl - NCH + 1);
+        constexpr bool is_last_c = ILV ? sl == NU - 2 : sl == NU - 1;
         const int allowed = st2 + (have1 ? nd1 : 0) + st1;
         switch(min(allowed, 63) >> 2)
         {
@@ -302,13 +316,14 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
         }
         __builtin_amdgcn_s_barrier(); // everybody's pieces of this unit have landed; everybody is done with the previous unit's buffer
         asm volatile("" ::: "memory");
-        const bool have2 = have1 && it < n_tiles;
+        const bool have2 = have1 && ij <= T;
         int nd2 = 0;
         if(have2)
         {
-            nd2 = issue(it, chunk_of_rt(iu), buf == 0 ? 2 : buf - 1, pc);
+            nd2 = issue_cursor(buf == 0 ? 2 : buf - 1, pc); // (buf + 2) % 3: the buffer the previous unit used
             advance_issue();
-            pc = lookup(chunk_of_rt(iu));
+            if(ij <= T)
+                pc = lookup(slot_chunk(isl)); // for the unit after that: off the critical path of the next barrier
         }
         const int kc = min(P3_KC, a.k_pad - P3_KC * cc);
         st2 = st1;
@@ -316,11 +331,11 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
         if(nvalid > 0)
         {
             int ty, x0;
-            tile_xy(ct, ty, x0);
-            if constexpr(is_m)
+            tile_xy(slot_tile(cj, sl), ty, x0);
+            if constexpr(!is_c)
             {
                 half8 wk[2] = {wreg[2 * cc], wreg[2 * cc + 1]};
-                compute(wk, buf, kc, std::integral_constant<bool, u == 0>{}); // the first chunk of a tile starts from a zero C operand
+                compute(wk, buf, kc, std::integral_constant<bool, sl == 0>{}); // the first chunk of a tile starts from a zero C operand
             }
             if constexpr(is_mc)
             {
@@ -351,7 +366,8 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                             const float dist = v - (t - 16384.0f);
                             const float pow2 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v + bmax_acc) & 0x7f800000u);
                             const float inside = __builtin_fmaf(-chain_acc, pow2, base_acc);
-                            mask[i] |= __builtin_fabsf(dist) > inside ? 1u << (3 * b + ch) : 0u;
+                            if constexpr(LFI_SX_ABL < 3)
+                                mask[i] |= __builtin_fabsf(dist) > inside ? 1u << (3 * b + ch) : 0u;
                             bits[ch] = __builtin_bit_cast(uint32_t, t);
                         }
                         const uint32_t rg = __builtin_amdgcn_perm(bits[1], bits[0], 0x0c0c0400u); // [R, G, 0, 0]
@@ -413,7 +429,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                     const bool spill = mine && slot >= SX_QCAP;
                     if(__builtin_amdgcn_ballot_w64(spill) != 0ull) // wave-uniform; rare (adversarial inputs: every sum a tie)
                     {
-                        // this lane's own sum, tap by tap from the planar copy (shift copy 0: pixel x at byte x + padx) and the weight table
+                        // this lane's own sum, tap by tap from the planar copy (pixel x at byte x + padx) and the weight table
                         const uint32_t b = (uint32_t(bit) * 11u) >> 5, ch = uint32_t(bit) - 3u * b;
                         const int x = x0 + 8 * n + int(b), y = a.out_y0 + ty;
                         const int view = vw0 + 4 * kg + i_sel;
@@ -425,7 +441,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                             {
                                 const int2 o = off_table[g];
                                 const int sy = clampi(y + o.y, 0, H - 1) - a.in_y0;
-                                const uint8_t p = a.planar[((size_t)g * 3 + ch) * 4 * shift_stride + (size_t)sy * a.planar_pitch + (x + o.x + a.planar_padx)];
+                                const uint8_t p = a.planar[((size_t)g * 3 + ch) * shift_stride + (size_t)sy * a.planar_pitch + (x + o.x + a.planar_padx)];
                                 const float w = static_cast<float>(__builtin_bit_cast(_Float16, wrow[g]));
                                 s = __builtin_fmaf(static_cast<float>(p), w, s);
                             }
@@ -434,34 +450,32 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                     }
                     count += __builtin_popcountll(m);
                 }
-                const int queued = min(count, SX_QCAP);
-                second_round = queued > 64;
-                const bool have0 = lane < queued, have1q = 64 + lane < queued;
-                const uint32_t code0 = queue[have0 ? lane : 0], code1 = queue[have1q ? 64 + lane : 0];
-                e0 = decode(have0 ? code0 : 0u, have0); // lanes without a sum run the chain on entry 0 and store nothing
-                e1 = decode(have1q ? code1 : 0u, have1q);
+                queued = min(count, SX_QCAP);
+                const uint32_t code0 = queue[lane < queued ? lane : 0], code1 = queue[64 + lane < queued ? 64 + lane : 0];
+                entry0 = lane < queued ? pack_entry(code0) : 0u; // lanes without a sum run the chain on entry 0 and store nothing
+                entry1 = 64 + lane < queued ? pack_entry(code1) : 0u;
+                s0 = s1 = 0.0f;
             }
-            if constexpr(!is_m || is_mc)
+            if constexpr((is_c || is_mc) && LFI_SX_ABL == 0)
             {
-                chain(std::integral_constant<int, cc>{}, buf, kc, e0);
-                if(second_round)
-                    chain(std::integral_constant<int, cc>{}, buf, kc, e1);
+                // chain over chunk cc for the queued sums: MC — chunk 0 of this tile, still in its buffer; C' — the previous tile's chunk
+                chain(std::integral_constant<int, cc>{}, buf, kc, entry0, s0);
+                if(queued > 64)
+                    chain(std::integral_constant<int, cc>{}, buf, kc, entry1, s1);
             }
-            if constexpr(is_last)
+            if constexpr(is_last_c)
             {
                 // the chain's bytes over the rounded ones (not counted in st1: an undercount is safe)
                 uint8_t *ubase = a.views + (((size_t)vw0 * a.out_rows + ty) * W + x0) * 4;
                 const size_t vstride = (size_t)a.out_rows * W * 4;
-                if(e0.have)
-                    (ubase + (size_t)e0.v16 * vstride)[e0.px * 4u + e0.ch] = static_cast<uint8_t>(byte_of(e0.s15));
-                if(second_round && e1.have)
-                    (ubase + (size_t)e1.v16 * vstride)[e1.px * 4u + e1.ch] = static_cast<uint8_t>(byte_of(e1.s15));
+                if(lane < queued)
+                    (ubase + (size_t)((entry0 >> 7) & 15u) * vstride)[(entry0 & 127u) * 4u + (entry0 >> 11)] = static_cast<uint8_t>(byte_of(s0));
+                if(64 + lane < queued)
+                    (ubase + (size_t)((entry1 >> 7) & 15u) * vstride)[(entry1 & 127u) * 4u + (entry1 >> 11)] = static_cast<uint8_t>(byte_of(s1));
             }
         }
         if(!have1)
             return false;
-        if constexpr(is_last)
-            ct += G;
         buf = buf == 2 ? 0 : buf + 1;
         have1 = have2;
         nd1 = nd2;
@@ -469,10 +483,13 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
     };
     bool more = true;
     while(more)
-        p3_for_each_chunk<NU>([&](auto u_tag) {
-            if(more)
-                more = unit(u_tag);
+    {
+        p3_for_each_chunk<NU>([&](auto sl_tag) {
+            if(more && slot_valid(cj, decltype(sl_tag)::value))
+                more = unit(sl_tag);
         });
+        cj++;
+    }
 }
 
 } // namespace lfi

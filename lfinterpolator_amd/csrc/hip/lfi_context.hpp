@@ -88,7 +88,7 @@ struct lfi_ctx
     // planar copy of the inputs for blend_planar (built on demand; valid while planar_version == grid_version)
     uint8_t *planar = nullptr;
     size_t planar_bytes = 0;
-    int planar_pitch = 0, planar_padx = 0;
+    int planar_pitch = 0, planar_padx = 0, planar_reach = 0; // bytes per plane row; left padding; the largest |x offset| it was built for
     uint64_t grid_version = 1, planar_version = 0;
     bool grid_tracked = true; // every write to the planes goes through this library (or is announced by lfi_grid_modified)
     void *focus_ws = nullptr; // workspace of the factored focus-map estimate (plan, E, K), allocated on first use

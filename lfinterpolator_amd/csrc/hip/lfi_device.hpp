@@ -48,8 +48,8 @@ struct KernelArgs
     int32_t n_focus_ids;
     int32_t radius_x, radius_y;             // constants[9..10]
     int32_t fo_min_x, fo_max_x, fo_min_y, fo_max_y; // bounds of focusedOffsets over the n_images images (interior-tile tests)
-    // planar copy of the inputs (blend_planar.hpp), or nullptr: [image][channel R,G,B][byte shift 0..3][H][planar_pitch] bytes,
-    // pixel x of a row at byte x + planar_padx − shift, edges replicated into the padding
+    // planar copy of the inputs (blend_planar.hpp), or nullptr: [image][channel R,G,B][rows held][planar_pitch] bytes,
+    // pixel x of a row at byte x + planar_padx, edges replicated into the padding
     const uint8_t *__restrict__ planar;
     int32_t planar_pitch, planar_padx;
     int32_t views_pitch;                    // planar view layout (blend_p3.hpp): bytes per row of a byte plane [view][R,G,B][out_rows][views_pitch]

@@ -129,12 +129,18 @@ void launch_std_filtered(const lfi_ctx *c, const KernelArgs &a_in, bool all_focu
             KernelArgs a = a_in;
             a.v0 = v0;
             a.v1 = std::min(v0 + 64, a_in.v1);
+#ifdef LFI_SX_ILV // measurement builds: the C units of a tile interleaved with the next tile's M units (blend_stdx.hpp)
+#define LFI_SX_LAUNCH(N) hipLaunchKernelGGL((lfi::blend_stdx<true, N, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse)
+#else
+#define LFI_SX_LAUNCH(N) hipLaunchKernelGGL((lfi::blend_stdx<true, N>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse)
+#endif
             switch(nch)
             {
-                case 2: hipLaunchKernelGGL((lfi::blend_stdx<true, 2>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse); break;
-                case 3: hipLaunchKernelGGL((lfi::blend_stdx<true, 3>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse); break;
-                default: hipLaunchKernelGGL((lfi::blend_stdx<true, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse); break;
+                case 2: LFI_SX_LAUNCH(2); break;
+                case 3: LFI_SX_LAUNCH(3); break;
+                default: LFI_SX_LAUNCH(4); break;
             }
+#undef LFI_SX_LAUNCH
         }
         return;
     }
@@ -247,18 +253,19 @@ bool ensure_planar(lfi_ctx *c)
     const int reach = std::max(std::max(std::abs(c->fo_min[0]), std::abs(c->fo_max[0])), 0);
     if(reach > 4 * c->width + 4096)
         return false;
-    // a tile's 128-byte run may start `reach` pixels left of column 0 and, for the ragged last tile of a row, end 127 pixels past
-    // the row plus `reach`: pad by reach + 128 on both sides
-    const int need = (reach + 128 + 3) / 4 * 4;
-    if(c->planar && c->planar_version == c->grid_version && c->planar_padx >= need)
+    // a tile's 128-byte run starts up to `reach` pixels left of column 0 (left padding: reach, rounded up to whole dwords so that the
+    // build's dword stores stay aligned) and, in the last tile of a row, ends up to `reach` pixels past the last tile's 128th pixel
+    if(c->planar && c->planar_version == c->grid_version && c->planar_reach >= reach)
         return true;
-    const int padx = std::max(need, c->planar_padx);
-    const int pitch = (c->width + 2 * padx + 15) / 16 * 16;
-    // blend_p3 addresses a row as (shift·rows + row)·pitch with 24-bit multiplies, and a lane's byte inside its octet of images (8
-    // images × 12 planes) with 32 bits
-    if(c->in_rows >= (1 << 22) || pitch >= (1 << 24) || (uint64_t)100 * c->in_rows * pitch >= (1ull << 32))
+    const int built_for = std::max(reach, c->planar_reach);
+    const int padx = (built_for + 3) / 4 * 4;
+    const int tiles_w = (c->width + 127) / 128 * 128;
+    const int pitch = (padx + tiles_w + built_for + 15) / 16 * 16;
+    // blend_p3 / blend_stdx address a row as row·pitch with a 24-bit multiply, and a lane's byte inside its octet of images (8 images
+    // × 3 planes, plus the row and the run) with 32 bits
+    if(c->in_rows >= (1 << 24) || pitch >= (1 << 24) || (uint64_t)26 * c->in_rows * pitch >= (1ull << 32))
         return false;
-    const size_t bytes = (size_t)c->n * 12 * c->in_rows * pitch; // the rows this context holds (a row window: band + halo)
+    const size_t bytes = (size_t)c->n * 3 * c->in_rows * pitch; // the rows this context holds (a row window: band + halo)
     if(bytes != c->planar_bytes)
     {
         if(c->planar)
@@ -275,6 +282,7 @@ bool ensure_planar(lfi_ctx *c)
         c->planar_bytes = bytes;
     }
     c->planar_padx = padx;
+    c->planar_reach = built_for;
     c->planar_pitch = pitch;
     hipLaunchKernelGGL(lfi::planar_build, dim3((pitch / 4 + 255) / 256, c->in_rows, c->n), dim3(256), 0, c->stream, c->grid, c->planar,
                        c->width, c->in_rows, pitch, padx);
