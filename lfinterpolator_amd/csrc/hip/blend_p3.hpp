@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
     for(int g = threadIdx.x; g < a.n_images; g += 64 * NW)
     {
         const lfi_int2 o = a.focused[g];
-        off_table[g] = make_int2(o.x, o.y);
+        off_table[g] = make_int2(o.x + a.planar_phase[g], o.y); // the image's phase inside the planar copy folded into its x offset
     }
 
     // this wave's 16 views of a pass (views v0 + 64·pass + 16·wave …): all their weights, as MFMA A fragments (k-step s = images

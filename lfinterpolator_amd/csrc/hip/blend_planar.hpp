@@ -38,17 +38,18 @@ namespace lfi {
 // grid (ceil(pitch/1024), H, N): a thread writes one dword (4 consecutive bytes) of the 3 planes of its image row
 // H = rows HELD per plane (the whole image, or the input rows of a row window)
 __global__ void __launch_bounds__(256) planar_build(const uint8_t *__restrict__ grid, uint8_t *__restrict__ planar, const int W, const int H,
-                                                    const int pitch, const int padx)
+                                                    const int pitch, const int padx, const int32_t *__restrict__ phase)
 {
     const int j4 = (blockIdx.x * 256 + threadIdx.x) * 4; // first byte column of this thread's dword
     if(j4 >= pitch)
         return;
     const int y = blockIdx.y, g = blockIdx.z;
     const uint32_t *row = reinterpret_cast<const uint32_t *>(grid) + ((size_t)g * H + y) * W;
-    uint32_t px[4]; // byte j of a plane row holds pixel j − padx, edges replicated
+    const int first = padx + phase[g]; // byte of pixel 0
+    uint32_t px[4]; // byte j of a plane row holds pixel j − first, edges replicated
 #pragma unroll
     for(int i = 0; i < 4; i++)
-        px[i] = row[clampi(j4 - padx + i, 0, W - 1)];
+        px[i] = row[clampi(j4 - first + i, 0, W - 1)];
 #pragma unroll
     for(int c = 0; c < 3; c++)
     {
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
     for(int g = threadIdx.x; g < a.n_images; g += 256)
     {
         const lfi_int2 o = a.focused[g];
-        off_table[g] = make_int2(o.x, o.y);
+        off_table[g] = make_int2(o.x + a.planar_phase[g], o.y); // the image's phase inside the planar copy folded into its x offset
     }
     const bool single_chunk = a.k_pad <= KC;
     const bool static_weights = single_chunk && view_passes == 1;

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
     for(int g = threadIdx.x; g < a.n_images; g += 64 * NW)
     {
         const lfi_int2 o = a.focused[g];
-        off_table[g] = make_int2(o.x, o.y);
+        off_table[g] = make_int2(o.x + a.planar_phase[g], o.y); // the image's phase inside the planar copy folded into its x offset
     }
     uint16_t *queue = reinterpret_cast<uint16_t *>(lds + QUEUE_OFF) + wave * SX_QCAP;
 

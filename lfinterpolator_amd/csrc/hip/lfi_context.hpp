@@ -89,6 +89,10 @@ struct lfi_ctx
     uint8_t *planar = nullptr;
     size_t planar_bytes = 0;
     int planar_pitch = 0, planar_padx = 0, planar_reach = 0; // bytes per plane row; left padding; the largest |x offset| it was built for
+    int32_t *d_planar_phase = nullptr;      // [LFI_MAX_IMAGES] per-image phase of the planar copy (device)
+    std::vector<int32_t> planar_phase;      // the same on the host (kept alive: the upload is asynchronous)
+    std::vector<lfi_int2> h_focused;        // the integer offsets of the current parameters (host copy)
+    unsigned launches_with_offsets = 0;     // fixed-focus launches since the integer offsets last changed
     uint64_t grid_version = 1, planar_version = 0;
     bool grid_tracked = true; // every write to the planes goes through this library (or is announced by lfi_grid_modified)
     void *focus_ws = nullptr; // workspace of the factored focus-map estimate (plan, E, K), allocated on first use
@@ -223,6 +227,7 @@ KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
     a.v1 = v1;
     a.n_focus_ids = c->n_focus_ids;
     a.planar = nullptr; // set by launch_blend when the copy is valid for this launch
+    a.planar_phase = c->d_planar_phase;
     // blend_planar<STDF>: chain bound N·2^-16 (half an ulp below 512 per fmaf: arithmetic) + MFMA accumulation bound N·2^-17 (a
     // quarter ulp per addend: MEASURED on gfx950 — chains of v_mfma_f32_32x32x16_f16 on operands built to expose alignment
     // truncation stay within 0.086 ulp per addend, tests/test_gpu_parity.py::test_mfma_f16_accumulation_error_bound asserts the
@@ -354,6 +359,9 @@ void free_grid(lfi_ctx *c)
     c->planar = nullptr;
     c->planar_bytes = 0;
     c->planar_version = 0;
+    if(c->d_planar_phase)
+        (void)hipFree(c->d_planar_phase);
+    c->d_planar_phase = nullptr;
 }
 
 } // namespace

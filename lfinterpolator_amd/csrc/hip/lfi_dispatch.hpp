@@ -246,7 +246,11 @@ int next_sweep_direction(const lfi_ctx *c)
 
 // Make the planar copy of the inputs valid for a fixed-focus launch with the current parameters; returns false (and leaves the
 // launch on the RGBA planes) when the copy may not be used: inputs the library cannot track, absurd offsets.
-bool ensure_planar(lfi_ctx *c)
+// tune: also make the copy's per-image phases fit the CURRENT integer offsets (every run then starts on a dword: ≈ 3–5 % faster
+// launches, tools/align_probe.py) — a rebuild.  lfi_prepare / lfi_benchmark ask for it; launch_blend asks once the same offsets have
+// been rendered a few times (the reference's 100-launch loop, a trajectory streamed at one focus), so a focus sweep — new offsets
+// every render — never pays a rebuild per render.
+bool ensure_planar(lfi_ctx *c, bool tune = false)
 {
     if(!c->grid_tracked)
         return false;
@@ -255,12 +259,19 @@ bool ensure_planar(lfi_ctx *c)
         return false;
     // a tile's 128-byte run starts up to `reach` pixels left of column 0 (left padding: reach, rounded up to whole dwords so that the
     // build's dword stores stay aligned) and, in the last tile of a row, ends up to `reach` pixels past the last tile's 128th pixel
-    if(c->planar && c->planar_version == c->grid_version && c->planar_reach >= reach)
+    const bool valid = c->planar && c->planar_version == c->grid_version && c->planar_reach >= reach && (int)c->planar_phase.size() == c->n;
+    auto tuned = [&] {
+        for(int g = 0; g < c->n; g++)
+            if((c->h_focused[g].x + c->planar_padx + c->planar_phase[g]) & 3)
+                return false;
+        return true;
+    };
+    if(valid && (!tune || tuned()))
         return true;
     const int built_for = std::max(reach, c->planar_reach);
     const int padx = (built_for + 3) / 4 * 4;
     const int tiles_w = (c->width + 127) / 128 * 128;
-    const int pitch = (padx + tiles_w + built_for + 15) / 16 * 16;
+    const int pitch = (padx + 3 + tiles_w + built_for + 15) / 16 * 16; // + 3: the largest phase
     // blend_p3 / blend_stdx address a row as row·pitch with a 24-bit multiply, and a lane's byte inside its octet of images (8 images
     // × 3 planes, plus the row and the run) with 32 bits
     if(c->in_rows >= (1 << 24) || pitch >= (1 << 24) || (uint64_t)26 * c->in_rows * pitch >= (1ull << 32))
@@ -281,15 +292,36 @@ bool ensure_planar(lfi_ctx *c)
         }
         c->planar_bytes = bytes;
     }
+    if(!c->d_planar_phase && hipMalloc(reinterpret_cast<void **>(&c->d_planar_phase), sizeof(int32_t) * LFI_MAX_IMAGES) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        c->d_planar_phase = nullptr;
+        return false;
+    }
+    // the phases: (offset + padx + phase) ≡ 0 mod 4 for the offsets in use now.  Synchronous upload of ≤ 1 KB: kernels of earlier
+    // launches that read the old phases are ordered before it on the stream, and the host vector may change right after.
+    c->planar_phase.assign(c->n, 0);
+    for(int g = 0; g < c->n; g++)
+        c->planar_phase[g] = (4 - ((c->h_focused[g].x + padx) & 3)) & 3;
+    c->planar_version = 0;
+    if(hipMemcpyAsync(c->d_planar_phase, c->planar_phase.data(), sizeof(int32_t) * c->n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+       hipStreamSynchronize(c->stream) != hipSuccess)
+        return false;
     c->planar_padx = padx;
     c->planar_reach = built_for;
     c->planar_pitch = pitch;
     hipLaunchKernelGGL(lfi::planar_build, dim3((pitch / 4 + 255) / 256, c->in_rows, c->n), dim3(256), 0, c->stream, c->grid, c->planar,
-                       c->width, c->in_rows, pitch, padx);
+                       c->width, c->in_rows, pitch, padx, c->d_planar_phase);
     if(hipGetLastError() != hipSuccess)
         return false;
     c->planar_version = c->grid_version;
     return true;
+}
+
+// launch_blend's policy for the rebuild above: the same integer offsets rendered for the third time
+bool tune_planar_now(lfi_ctx *c)
+{
+    return c->launches_with_offsets++ >= 2;
 }
 
 // Would this launch read the planar copy of the inputs?  It pays where reads are a large share of the traffic: not for launches
@@ -404,12 +436,13 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
         return rc;
     if(c->out_layout != LFI_LAYOUT_PLANAR_RGB)
         return launch_blend_rgba(c, method, all_focus, a_in);
-    if(wants_p3(c, method, all_focus, a_in) && ensure_planar(c))
+    if(wants_p3(c, method, all_focus, a_in) && ensure_planar(c, tune_planar_now(c)))
     {
         KernelArgs a = a_in;
         a.planar = c->planar;
         a.planar_pitch = c->planar_pitch;
         a.planar_padx = c->planar_padx;
+        a.planar_phase = c->d_planar_phase; // allocated by ensure_planar, possibly just now
         launch_p3(c, a);
         LFI_HIP(c, hipGetLastError());
         return LFI_OK;
@@ -441,11 +474,12 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
 int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
 {
     KernelArgs a = a_in;
-    if(wants_planar(c, method, all_focus, a) && ensure_planar(c))
+    if(wants_planar(c, method, all_focus, a) && ensure_planar(c, tune_planar_now(c)))
     {
         a.planar = c->planar;
         a.planar_pitch = c->planar_pitch;
         a.planar_padx = c->planar_padx;
+        a.planar_phase = c->d_planar_phase; // allocated by ensure_planar, possibly just now
     }
     if(c->windowed)
     {

@@ -512,6 +512,9 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     ctx->views_n = V;
     ctx->n_focus_ids = p->n_focus_ids;
     ctx->h_offsets.assign(p->offsets, p->offsets + n);
+    if((int)ctx->h_focused.size() != n || std::memcmp(ctx->h_focused.data(), p->focused_offsets, sizeof(lfi_int2) * n) != 0)
+        ctx->launches_with_offsets = 0; // new integer offsets: the planar copy's phases may no longer fit them (ensure_planar)
+    ctx->h_focused.assign(p->focused_offsets, p->focused_offsets + n);
     ctx->h_focus_offsets.clear();
     for(int k = 0; k < p->n_focus_ids; k++)
         ctx->h_focus_offsets.push_back(p->offsets[p->focus_map_ids[k]]);
@@ -701,7 +704,7 @@ int lfi_prepare(lfi_ctx *ctx, int method, int all_focus, int v0, int v1)
     {
         const uint64_t before = ctx->planar_version;
         LFI_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        const bool ok = ensure_planar(ctx);
+        const bool ok = ensure_planar(ctx, true);
         LFI_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         LFI_HIP(ctx, hipEventSynchronize(ctx->ev1));
         if(ok && ctx->planar_version != before)
@@ -920,7 +923,7 @@ int lfi_benchmark(lfi_ctx *ctx, int method, int all_focus, int v0, int v1, int w
     const KernelArgs a = make_args(ctx, v0, v1, method);
     // the derived input copy is (re)built here, not inside the first timed launch
     if(wants_derived_copy(ctx, method, all_focus, a))
-        (void)ensure_planar(ctx);
+        (void)ensure_planar(ctx, true);
     for(int i = 0; i < warmup; i++)
         if(int rc = launch_blend(ctx, method, all_focus, a))
             return rc;
