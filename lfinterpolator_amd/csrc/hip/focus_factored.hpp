@@ -18,16 +18,20 @@
 //   row y flagged, column not:  the tap rows are whatever the reference computes for (y, view), the tap columns are
 //       uniform shifts → three lines E'(i, y, ty)(qx) (focus_lines_rows), nine samples of those (focus_line_keys → K);
 //   column x flagged, row not:  three lines E''(i, x, tx)(qy) (focus_lines_cols), likewise;
-//   both flagged (or more flagged rows / columns than the line buffers hold): tap by tap, focus_exact → K.
+//   both flagged: the taps where BOTH axes fail (usually one) tap by tap (focus_exact), the others from the lines / E as above;
+//   more flagged rows / columns than the line buffers hold: all nine taps tap by tap, focus_exact → K.
 // focus_pick takes K instead of the factored sum wherever a flag is set.
 // The integer key (16·S + k, see focus_map.hpp) is the same as in the other variants, so results are bit-identical.
 //
 // Clamp-to-edge is taken out of the hot loops: focus_pad copies the ≤32 sampled images into planes padded by the largest
 // shift + r on every side (edge pixels replicated), so every sample is an unclamped load at scalar base + lane offset.
 //
-// Passes (all on the context's stream):  plan_shifts → plan_flags → plan_lists → plan_prefix, focus_pad → focus_range (E),
-// focus_flagged = {focus_lines_rows (Er), focus_lines_cols (Ec), focus_exact (K)} → focus_line_keys (K) → focus_pick (map 0) →
-// focus_filter (map 1).
+// Flags are kept per tap (round 3): a line is computed only for the taps where the uniform shift fails — almost always the one tap
+// at +r — and the other taps of a flagged row / column are read from E like everybody else's.
+//
+// Passes:  plan_shifts → plan_flags → plan_lists → plan_prefix, focus_pad → focus_range (E),
+// focus_flagged = {focus_lines_rows (Er), focus_lines_cols (Ec), focus_exact (K)} → focus_line_keys (K; reads Er, Ec AND E) →
+// focus_pick (map 0) → focus_filter (map 1).
 #pragma once
 
 #include "focus_map.hpp"
@@ -42,6 +46,8 @@ struct FocusWork
     int32_t *shifts;    // [32][32][4]  sx, sy, image id (−1: unused slot), 0
     uint32_t *badx;     // [W]   bit i: column x needs the exact path for candidate i
     uint32_t *bady;     // [H]
+    uint32_t *tapx;     // [3][W] bit i: tap tx = t − 1 of column x is where the uniform shift fails for candidate i (badx = the OR of the three)
+    uint32_t *tapy;     // [3][H]
     uint16_t *cols;     // [32][W]  flagged columns of candidate i, ascending
     uint16_t *rows;     // [32][H]
     int32_t *ncols;     // [32]
@@ -129,7 +135,9 @@ __global__ void __launch_bounds__(256) focus_plan_flags(const KernelArgs a, cons
         return;
     const int r = axis ? a.radius_y : a.radius_x;
     const float f = focus_candidate(a, i);
-    bool bad = false;
+    // per tap: almost every flag comes from truncation toward zero left of / above the image, which moves only the tap at +r (the
+    // taps at −r and 0 clamp to the edge either way) — the line passes then compute one line per flagged row / column, not three
+    bool bad[3] = {false, false, false};
     for(int k = 0; k < a.n_focus_ids; k++)
     {
         const int32_t *s = w.shifts + 4 * (i * FOCUS_MAX_IDS + k);
@@ -138,10 +146,14 @@ __global__ void __launch_bounds__(256) focus_plan_flags(const KernelArgs a, cons
         const int U = c + s[axis];
 #pragma unroll
         for(int t = -1; t <= 1; t++)
-            bad = bad || (clampi(T + t * r, 0, L - 1) != clampi(U + t * r, 0, L - 1));
+            bad[t + 1] = bad[t + 1] || (clampi(T + t * r, 0, L - 1) != clampi(U + t * r, 0, L - 1));
     }
-    if(bad)
+    if(bad[0] || bad[1] || bad[2])
         atomicOr((axis ? w.bady : w.badx) + c, 1u << i);
+#pragma unroll
+    for(int t = 0; t < 3; t++)
+        if(bad[t])
+            atomicOr((axis ? w.tapy : w.tapx) + (size_t)t * L + c, 1u << i);
 }
 
 // line slot of a flagged (row or column c, candidate i) pair
@@ -522,6 +534,11 @@ __device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const Focu
             const int sx_l = w.shifts[4 * (i * FOCUS_MAX_IDS + kk)];
             const int row_l = warp_float(y, f, offy_l) - a.radius_y + w.Py;
             const uint64_t off_l = (((uint64_t)kk * w.Hp + row_l) * w.Wp + uint64_t(int(tile) * 256 - a.radius_x + w.Px + sx_l)) * 4u;
+            // the taps (ty = t − 1) of this row that need their own line for this candidate: wave-uniform, usually just t = 2
+            uint32_t tm = 0u;
+#pragma unroll
+            for(int t = 0; t < 3; t++)
+                tm |= ((__builtin_amdgcn_readfirstlane(w.tapy[(size_t)t * a.height + y]) >> i) & 1u) << t;
             RangeAcc4 acc[3];
 #pragma unroll
             for(int t = 0; t < 3; t++)
@@ -531,13 +548,17 @@ __device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const Focu
                 const uint8_t *p = pad + readlane64(off_l, k);
 #pragma unroll
                 for(int t = 0; t < 3; t++)
-                    v[t] = *reinterpret_cast<const u32x4_a4 *>(p + t * tap_stride);
+                    if(tm & (1u << t)) // wave-uniform
+                        v[t] = *reinterpret_cast<const u32x4_a4 *>(p + t * tap_stride);
+                    else
+                        v[t] = u32x4{0u, 0u, 0u, 0u};
             };
             // two views per reduction (min3 / max3); past the last view the index clamps to it (reducing a view twice changes nothing)
             auto reduce2 = [&](const u32x4 (&va)[3], const u32x4 (&vb)[3]) {
 #pragma unroll
                 for(int t = 0; t < 3; t++)
-                    acc[t].add2(va[t], vb[t]);
+                    if(tm & (1u << t))
+                        acc[t].add2(va[t], vb[t]);
             };
             const int last = n_ids - 1;
             u32x4 cur2[3], nxt2[3];
@@ -559,10 +580,11 @@ __device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const Focu
             reduce2(cur2, nxt2);
 #pragma unroll
             for(int t = 0; t < 3; t++)
-            {
-                uint16_t *dst = w.Er + ((size_t)slot * 3 + t) * w.We_p + tile * 256 + 4 * lane;
-                *reinterpret_cast<u32x2 *>(dst) = acc[t].encode();
-            }
+                if(tm & (1u << t)) // the other lines of the slot stay unwritten: focus_line_keys takes those taps from E
+                {
+                    uint16_t *dst = w.Er + ((size_t)slot * 3 + t) * w.We_p + tile * 256 + 4 * lane;
+                    *reinterpret_cast<u32x2 *>(dst) = acc[t].encode();
+                }
         }
     }
 }
@@ -613,16 +635,26 @@ __device__ __forceinline__ void focus_lines_cols(const KernelArgs &a, const Focu
 #pragma unroll
             for(int t = 0; t < 3; t++)
                 acc[r][t].init();
+        // the taps (tx = t − 1) of this lane's column that need their own line for this candidate (per lane; usually just t = 2): the
+        // other loads are masked off — an inactive lane makes no request — and their lines stay unwritten (focus_line_keys reads E there)
+        uint32_t tm = 0u;
+#pragma unroll
+        for(int t = 0; t < 3; t++)
+            tm |= ((w.tapx[(size_t)t * a.width + x] >> i) & 1u) << t;
+        tm = active ? tm : 0u;
         uint32_t cur[R][3], nxt[R][3];
         auto fetch = [&](const int k, uint32_t (&v)[R][3]) {
             const float offx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(uint32_t, offx_l), k));
             const uint32_t left = uint32_t(warp_float(x, f, offx) - rx + w.Px) * 4u; // tx = 0 sample column, bytes
             const uint8_t *row = pad + readlane64(off_l, k);
 #pragma unroll
-            for(int r = 0; r < R; r++)
+            for(int t = 0; t < 3; t++)
+            {
+                const bool want = (tm >> t) & 1u;
 #pragma unroll
-                for(int t = 0; t < 3; t++)
-                    v[r][t] = *reinterpret_cast<const uint32_t *>(row + r * row_bytes + uint32_t(t * rx) * 4u + left);
+                for(int r = 0; r < R; r++)
+                    v[r][t] = want ? *reinterpret_cast<const uint32_t *>(row + r * row_bytes + uint32_t(t * rx) * 4u + left) : 0u;
+            }
         };
         auto reduce2 = [&](const uint32_t (&va)[R][3], const uint32_t (&vb)[R][3]) { // two views per reduction (min3 / max3)
 #pragma unroll
@@ -655,18 +687,21 @@ __device__ __forceinline__ void focus_lines_cols(const KernelArgs &a, const Focu
             for(int r = 0; r < R; r++)
 #pragma unroll
                 for(int t = 0; t < 3; t++)
-                {
-                    uint32_t range, tiny;
-                    acc[r][t].result(range, tiny);
-                    w.Ec[((size_t)t * w.He_p + rb * R + r) * w.C_cap + cs] = static_cast<uint16_t>((range << 4) + tiny);
-                }
+                    if((tm >> t) & 1u)
+                    {
+                        uint32_t range, tiny;
+                        acc[r][t].result(range, tiny);
+                        w.Ec[((size_t)t * w.He_p + rb * R + r) * w.C_cap + cs] = static_cast<uint16_t>((range << 4) + tiny);
+                    }
         }
     }
 }
 
 // exact key of one (pixel, candidate): the reference's arithmetic tap by tap, in the integer formulation of focus_map.hpp.
 // Samples come from the padded planes: the unclamped coordinate, offset by (Px, Py), holds the clamp-to-edge value.
-__device__ __forceinline__ uint32_t focus_exact_key(const KernelArgs &a, const FocusWork &w, const int x, const int y, const int i)
+// m9: the taps to compute (bit 3·tx + ty, per lane; the other taps' loads are masked off).  Returns Σ over those taps of
+// 16·range + (FLT_MIN tap ? 1 : 0) — with all nine taps, focus_key_encode of it is the pixel's key.
+__device__ __forceinline__ uint32_t focus_exact_taps(const KernelArgs &a, const FocusWork &w, const int x, const int y, const int i, const uint32_t m9)
 {
     const int rx = a.radius_x, ry = a.radius_y;
     const float f = focus_candidate(a, i);
@@ -695,19 +730,27 @@ __device__ __forceinline__ uint32_t focus_exact_key(const KernelArgs &a, const F
             for(int tx = 0; tx < 3; tx++)
             {
                 const uint32_t tap = uint32_t(ty * ry * w.Wp + tx * rx) * 4u;
-                acc[tx * 3 + ty].add2(*reinterpret_cast<const uint32_t *>(ca + tap), *reinterpret_cast<const uint32_t *>(cb + tap));
+                const bool want = (m9 >> (tx * 3 + ty)) & 1u;
+                const uint32_t pa = want ? *reinterpret_cast<const uint32_t *>(ca + tap) : 0u;
+                const uint32_t pb = want ? *reinterpret_cast<const uint32_t *>(cb + tap) : 0u;
+                acc[tx * 3 + ty].add2(pa, pb);
             }
     }
-    uint32_t S = 0, kmin = 0;
+    uint32_t sum = 0;
 #pragma unroll
     for(int t = 0; t < 9; t++)
     {
         uint32_t range, tiny;
         acc[t].result(range, tiny);
-        S += range;
-        kmin += tiny;
+        sum += ((m9 >> t) & 1u) ? (range << 4) + tiny : 0u;
     }
-    return S > 0 ? (S << 4) : kmin;
+    return sum;
+}
+
+// the key of a pixel from the sum of its nine taps' 16·range + tiny: 16·S if any range is non-zero, else the FLT_MIN count (focus_map.hpp)
+__device__ __forceinline__ uint32_t focus_key_encode(const uint32_t sum)
+{
+    return sum >= 16u ? (sum & ~15u) : sum;
 }
 
 // Tap-by-tap keys for what the line buffers do not cover.  Persistent, three unit sequences:
@@ -724,19 +767,37 @@ __device__ __forceinline__ void focus_exact(const KernelArgs &a, const FocusWork
     const focus_const_int_ptr ncols = (focus_const_int_ptr)(uintptr_t)w.ncols;
     const uint32_t row_entries = prefix[32], col_entries = prefix[65];
 
-    auto columns = [&](const int i, const int y, const bool overflow_only) { // flagged columns of candidate i in row y
+    // flagged columns of candidate i in row y.  A pair whose row AND column both have a line slot gets only its CORNER taps here — the
+    // taps where the uniform shift fails on both axes, usually the one at (+r, +r) — as a raw partial sum; focus_line_keys adds the
+    // other taps from the row's lines, the column's lines and E.  Pairs without a slot on either axis get all nine taps (the whole key).
+    auto columns = [&](const int i, const int y, const bool overflow_only) {
         const int n = ncols[i];
+        const bool row_has_slot = __builtin_amdgcn_readfirstlane(line_slot(w.rowbase[y], w.bady[y], i)) < uint32_t(w.R_cap);
+        uint32_t tmy = 0u; // wave-uniform
+#pragma unroll
+        for(int t = 0; t < 3; t++)
+            tmy |= ((__builtin_amdgcn_readfirstlane(w.tapy[(size_t)t * H + y]) >> i) & 1u) << t;
         for(int idx = lane; idx - lane < n; idx += 64)
         {
             bool active = idx < n;
             const int x = active ? w.cols[(size_t)i * W + idx] : 0;
+            const bool col_has_slot = line_slot(w.colbase[x], w.badx[x], i) < uint32_t(w.C_cap);
             if(overflow_only)
-                active = active && line_slot(w.colbase[x], w.badx[x], i) >= uint32_t(w.C_cap);
+                active = active && !col_has_slot;
             if(__builtin_amdgcn_ballot_w64(active) == 0ull)
                 continue;
-            const uint32_t key = focus_exact_key(a, w, x, y, i);
+            const bool whole = overflow_only || !row_has_slot || !col_has_slot;
+            uint32_t m9 = 0x1ffu;
+            if(!whole)
+            {
+                m9 = 0u;
+#pragma unroll
+                for(int tx = 0; tx < 3; tx++)
+                    m9 |= ((w.tapx[(size_t)tx * W + x] >> i) & 1u) ? tmy << (3 * tx) : 0u;
+            }
+            const uint32_t sum = focus_exact_taps(a, w, x, y, i, active ? m9 : 0u);
             if(active)
-                w.K[((size_t)i * H + y) * W + x] = static_cast<uint16_t>(key);
+                w.K[((size_t)i * H + y) * W + x] = static_cast<uint16_t>(whole ? focus_key_encode(sum) : sum);
         }
     };
     // (A)
@@ -760,7 +821,7 @@ __device__ __forceinline__ void focus_exact(const KernelArgs &a, const FocusWork
                 continue;
             const int xx = int(u % chunks_w) * 64 + lane;
             const bool active = xx < W;
-            const uint32_t key = focus_exact_key(a, w, active ? xx : 0, y, i);
+            const uint32_t key = focus_key_encode(focus_exact_taps(a, w, active ? xx : 0, y, i, active ? 0x1ffu : 0u));
             if(active)
                 w.K[((size_t)i * H + y) * W + xx] = static_cast<uint16_t>(key);
         }
@@ -774,9 +835,9 @@ __device__ __forceinline__ void focus_exact(const KernelArgs &a, const FocusWork
 // The three passes over flagged pairs are independent, small and latency-bound: one launch, the workgroups split between
 // them (gridDim.x = 3·per_pass, per_pass a multiple of 8), so that they run side by side — next to focus_range on the
 // main stream — instead of one after the other.
-__global__ void __launch_bounds__(256) focus_flagged(const KernelArgs a, const FocusWork w, const uint32_t per_pass)
+__global__ void __launch_bounds__(256) focus_flagged(const KernelArgs a, const FocusWork w, const uint32_t per_pass, const uint32_t first_pass)
 {
-    const uint32_t pass = blockIdx.x / per_pass, block = blockIdx.x % per_pass; // wave-uniform
+    const uint32_t pass = first_pass + blockIdx.x / per_pass, block = blockIdx.x % per_pass; // wave-uniform
     if(pass == 0)
         focus_lines_rows(a, w, block, per_pass);
     else if(pass == 1)
@@ -798,7 +859,7 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
     const focus_const_u32_ptr prefix = (focus_const_u32_ptr)(uintptr_t)w.prefix;
     const focus_const_u32_ptr chunk_prefix = prefix + 66;
     const focus_const_int_ptr ncols = (focus_const_int_ptr)(uintptr_t)w.ncols;
-    auto encode = [](const uint32_t sum) { return sum >= 16u ? (sum & ~15u) : sum; };
+    auto encode = [](const uint32_t sum) { return focus_key_encode(sum); };
     // (R)
     const uint32_t chunks_w = uint32_t((W + 63) / 64);
     int i = 0;
@@ -813,13 +874,17 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
         const int x = int(u % chunks_w) * 64 + lane;
         if(x >= W || ((w.badx[x] >> i) & 1u))
             continue; // flagged on both axes: focus_exact (A)
-        const uint16_t *line = w.Er + (size_t)slot * 3 * w.We_p + x;
+        // per tap row: the row's own line where the uniform shift fails for it (wave-uniform), the candidate's plane of E otherwise
         uint32_t sum = 0;
 #pragma unroll
         for(int ty = 0; ty < 3; ty++)
+        {
+            const bool own = (__builtin_amdgcn_readfirstlane(w.tapy[(size_t)ty * H + y]) >> i) & 1u;
+            const uint16_t *line = own ? w.Er + ((size_t)slot * 3 + ty) * w.We_p + x : w.E + ((size_t)i * w.He_p + y + ty * ry) * w.We_p + x;
 #pragma unroll
             for(int tx = 0; tx < 3; tx++)
-                sum += line[(size_t)ty * w.We_p + tx * rx];
+                sum += line[tx * rx];
+        }
         w.K[((size_t)i * H + y) * W + x] = static_cast<uint16_t>(encode(sum));
     }
     // (C)
@@ -837,6 +902,10 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
         const uint32_t cs = line_slot(w.colbase[x], w.badx[x], ci);
         if(cs >= uint32_t(w.C_cap))
             continue; // focus_exact (C)
+        bool own[3]; // per tap column (per lane): the column's own line, or the candidate's plane of E
+#pragma unroll
+        for(int tx = 0; tx < 3; tx++)
+            own[tx] = (w.tapx[(size_t)tx * W + x] >> ci) & 1u;
         for(int y = int(rb) * ROWS; y < min(int(rb) * ROWS + ROWS, H); y++)
         {
             if((w.bady[y] >> ci) & 1u)
@@ -846,8 +915,53 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
             for(int tx = 0; tx < 3; tx++)
 #pragma unroll
                 for(int ty = 0; ty < 3; ty++)
-                    sum += w.Ec[((size_t)tx * w.He_p + y + ty * ry) * w.C_cap + cs];
+                    sum += own[tx] ? w.Ec[((size_t)tx * w.He_p + y + ty * ry) * w.C_cap + cs] : w.E[((size_t)ci * w.He_p + y + ty * ry) * w.We_p + x + tx * rx];
             w.K[((size_t)ci * H + y) * W + x] = static_cast<uint16_t>(encode(sum));
+        }
+    }
+    // (A') pairs flagged on both axes whose row and column both have a line slot: focus_exact left the corner taps' partial sum in K;
+    // the other taps come from the row's own lines (ty flagged), the column's own lines (tx flagged) or E (neither)
+    int ai = 0;
+    for(uint32_t entry = wave_id; entry < prefix[32]; entry += n_waves)
+    {
+        prefix_walk(prefix, entry, ai);
+        const int y = __builtin_amdgcn_readfirstlane(int(w.rows[(size_t)ai * H + (entry - prefix[ai])]));
+        const uint32_t rs = __builtin_amdgcn_readfirstlane(line_slot(w.rowbase[y], w.bady[y], ai));
+        if(rs >= uint32_t(w.R_cap))
+            continue; // focus_exact wrote whole keys for this row
+        bool owny[3]; // wave-uniform
+#pragma unroll
+        for(int t = 0; t < 3; t++)
+            owny[t] = (__builtin_amdgcn_readfirstlane(w.tapy[(size_t)t * H + y]) >> ai) & 1u;
+        const int nc = ncols[ai];
+        for(int idx = lane; idx < nc; idx += 64)
+        {
+            const int x = w.cols[(size_t)ai * W + idx];
+            const uint32_t cs = line_slot(w.colbase[x], w.badx[x], ai);
+            if(cs >= uint32_t(w.C_cap))
+                continue; // a whole key
+            uint16_t *kp = w.K + ((size_t)ai * H + y) * W + x;
+            uint32_t sum = *kp;
+#pragma unroll
+            for(int tx = 0; tx < 3; tx++)
+            {
+                const bool ownx = (w.tapx[(size_t)tx * W + x] >> ai) & 1u;
+#pragma unroll
+                for(int ty = 0; ty < 3; ty++)
+                {
+                    if(ownx && owny[ty])
+                        continue; // a corner tap: in the partial sum
+                    uint32_t v;
+                    if(owny[ty]) // the row's own line (uniform shift in x)
+                        v = w.Er[((size_t)rs * 3 + ty) * w.We_p + x + tx * rx];
+                    else if(ownx) // the column's own line (uniform shift in y)
+                        v = w.Ec[((size_t)tx * w.He_p + y + ty * ry) * w.C_cap + cs];
+                    else
+                        v = w.E[((size_t)ai * w.He_p + y + ty * ry) * w.We_p + x + tx * rx];
+                    sum += v;
+                }
+            }
+            *kp = static_cast<uint16_t>(encode(sum));
         }
     }
 }

@@ -40,7 +40,7 @@ struct lfi_ctx
     hipEvent_t ev_uploads = nullptr;
     // side stream of the factored focus-map estimate (its small passes overlap the large ones), created on first use
     hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_pad = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_pad = nullptr, ev_join = nullptr, ev_range = nullptr;
     int cols = 0, rows = 0, n = 0, width = 0, height = 0;
     // row window (lfi_set_row_window): input rows held / output rows rendered; the whole image by default
     int in_y0 = 0, in_rows = 0, out_y0 = 0, out_rows = 0;

@@ -45,6 +45,7 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     };
     const size_t o_shifts = carve(sizeof(int32_t) * 4 * lfi::FOCUS_STEPS * lfi::FOCUS_MAX_IDS);
     const size_t o_badx = carve(sizeof(uint32_t) * W), o_bady = carve(sizeof(uint32_t) * H);
+    const size_t o_tapx = carve(sizeof(uint32_t) * 3 * W), o_tapy = carve(sizeof(uint32_t) * 3 * H); // cleared with badx / bady: adjacent
     const size_t o_cols = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * W), o_rows = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * H);
     const size_t o_ncols = carve(sizeof(int32_t) * lfi::FOCUS_STEPS), o_nrows = carve(sizeof(int32_t) * lfi::FOCUS_STEPS);
     const size_t o_prefix = carve(sizeof(uint32_t) * 3 * 33);
@@ -72,6 +73,8 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     w.shifts = reinterpret_cast<int32_t *>(base + o_shifts);
     w.badx = reinterpret_cast<uint32_t *>(base + o_badx);
     w.bady = reinterpret_cast<uint32_t *>(base + o_bady);
+    w.tapx = reinterpret_cast<uint32_t *>(base + o_tapx);
+    w.tapy = reinterpret_cast<uint32_t *>(base + o_tapy);
     w.cols = reinterpret_cast<uint16_t *>(base + o_cols);
     w.rows = reinterpret_cast<uint16_t *>(base + o_rows);
     w.ncols = reinterpret_cast<int32_t *>(base + o_ncols);
@@ -87,8 +90,8 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     w.pad = reinterpret_cast<uint32_t *>(base + o_pad);
     // Two streams: the plan and the flagged-pair passes are small, latency-bound kernels; they run beside the padded copy
     // and the range pass (bandwidth / VALU bound) instead of in front of them.
-    //   main:  plan_shifts ─┬─ pad ─┬─ range ───────────────────────────────┬─ pick (→ filter, by the caller)
-    //   aux:                └─ flags → lists → prefix ─┴─ {lines_rows, lines_cols, exact} → line_keys ─────┘
+    //   main:  plan_shifts ─┬─ pad ─┬─ range ──────────────────────────┬──────────────┬─ pick (→ filter, by the caller)
+    //   aux:                └─ flags → lists → prefix ─┴─ {lines_rows, lines_cols, exact} ─┴─ line_keys ─┘
     if(!ctx->aux_stream)
     {
         int prio_low = 0, prio_high = 0; // numerically lower = higher priority: the small passes should not queue behind the big ones
@@ -97,6 +100,7 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
         LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pad, hipEventDisableTiming));
         LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_range, hipEventDisableTiming));
     }
     hipStream_t st = ctx->stream;
     hipStream_t aux = ctx->aux_stream;
@@ -112,16 +116,23 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
         const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(tiles_x, tiles_y, GROUPS) : tiles_x * tiles_y * GROUPS;
         hipLaunchKernelGGL(lfi::focus_range<CPW>, dim3(nblocks), dim3(256), 0, st, a, w, nblocks, striped);
     }
+    LFI_HIP(ctx, hipEventRecord(ctx->ev_range, st));
     LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_fork, 0));
-    LFI_HIP(ctx, hipMemsetAsync(w.badx, 0, o_cols - o_badx, aux)); // badx and bady are adjacent
+    LFI_HIP(ctx, hipMemsetAsync(w.badx, 0, o_cols - o_badx, aux)); // badx, bady, tapx, tapy are adjacent
     hipLaunchKernelGGL(lfi::focus_plan_flags, dim3((std::max(W, H) + 255) / 256, lfi::FOCUS_STEPS, 2), dim3(256), 0, aux, a, w);
     hipLaunchKernelGGL(lfi::focus_plan_lists, dim3(lfi::FOCUS_STEPS, 2), dim3(64), 0, aux, a, w);
     hipLaunchKernelGGL(lfi::focus_plan_prefix, dim3(1), dim3(1), 0, aux, a, w);
     LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_pad, 0));
     {
         const uint32_t per_pass = uint32_t(ctx->cu_count) * 4u / 8u * 8u;
-        hipLaunchKernelGGL(lfi::focus_flagged, dim3(3 * per_pass), dim3(256), 0, aux, a, w, per_pass);
+#ifdef LFI_MEASUREMENT_BUILD // one launch per pass, so that a kernel trace shows what each of the three costs
+        for(uint32_t pass = 0; pass < 3; pass++)
+            hipLaunchKernelGGL(lfi::focus_flagged, dim3(per_pass), dim3(256), 0, aux, a, w, per_pass, pass);
+#else
+        hipLaunchKernelGGL(lfi::focus_flagged, dim3(3 * per_pass), dim3(256), 0, aux, a, w, per_pass, 0u);
+#endif
     }
+    LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_range, 0)); // the keys of single-axis pairs take their unflagged taps from E
     hipLaunchKernelGGL(lfi::focus_line_keys, dim3(ctx->cu_count * 8), dim3(256), 0, aux, a, w);
     LFI_HIP(ctx, hipEventRecord(ctx->ev_join, aux));
     LFI_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));

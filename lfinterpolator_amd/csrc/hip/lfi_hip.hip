@@ -110,6 +110,8 @@ int lfi_destroy(lfi_ctx *ctx)
         (void)hipEventDestroy(ctx->ev_pad);
     if(ctx->ev_join)
         (void)hipEventDestroy(ctx->ev_join);
+    if(ctx->ev_range)
+        (void)hipEventDestroy(ctx->ev_range);
     if(ctx->aux_stream)
         (void)hipStreamDestroy(ctx->aux_stream);
     if(ctx->own_stream)
