@@ -183,7 +183,7 @@ int lfi_set_output_layout(lfi_ctx *ctx, int layout);
 typedef struct lfi_view_layout_info {
     int32_t layout;            /* LFI_LAYOUT_* */
     int32_t rows;              /* rows per plane */
-    size_t row_pitch_bytes;    /* RGBA: W*4; planar: W rounded up to 16 */
+    size_t row_pitch_bytes;    /* RGBA: W*4; planar: W rounded up to 128 (every plane row starts on a cache line) */
     size_t plane_stride_bytes; /* planar: bytes from a view's R plane to its G plane; RGBA: 0 */
     size_t view_stride_bytes;  /* bytes from view v to view v+1 */
 } lfi_view_layout_info;

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -110,7 +111,57 @@ namespace {
 // lines, non-temporal stores), and planes that bypass the caches leave more of the Infinity Cache to the inputs the next launch
 // re-reads (tools/views_mtype.py, config 2: 150 µs against 156 µs per launch).  RGBA views stay in ordinary memory (the STD band
 // epilogue patches single bytes behind its dword stores).  LFI_VIEWS_MEMORY=default|uncached|finegrained overrides (experiments).
-hipError_t alloc_views(uint8_t **out, size_t bytes, bool planar_layout)
+//
+// Uncached blocks are NEVER handed back to the HIP runtime while the process lives (round 3).  Freed with hipFree, their address range
+// is recycled for later ordinary allocations — and contexts created after a few such cycles rendered garbage from ordinary memory
+// (inputs, parameters or RGBA views landing on a range that had been uncached: `tools/dbg_ragged.py`, reproduced three times out of
+// three with uncached views, never with ordinary or fine-grained ones; found when the view pitch changed the allocation sizes and the
+// planar row-band tests started to fail).  So released blocks go to a process-wide free list and are only ever reused as uncached views.
+struct UncachedBlock
+{
+    void *ptr;
+    size_t bytes;
+    int device;
+    bool in_use;
+};
+std::mutex g_uncached_mutex;
+std::vector<UncachedBlock> g_uncached_blocks;
+
+hipError_t uncached_alloc(uint8_t **out, size_t bytes, int device)
+{
+    std::lock_guard<std::mutex> lock(g_uncached_mutex);
+    UncachedBlock *best = nullptr;
+    for(UncachedBlock &b : g_uncached_blocks)
+        if(!b.in_use && b.device == device && b.bytes >= bytes && (!best || b.bytes < best->bytes))
+            best = &b;
+    if(best)
+    {
+        best->in_use = true;
+        *out = static_cast<uint8_t *>(best->ptr);
+        return hipSuccess;
+    }
+    void *p = nullptr;
+    const hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if(e != hipSuccess)
+        return e;
+    g_uncached_blocks.push_back(UncachedBlock{p, bytes, device, true});
+    *out = static_cast<uint8_t *>(p);
+    return hipSuccess;
+}
+
+bool uncached_release(void *p) // true: p was one of ours (kept for reuse); false: an ordinary allocation, the caller frees it
+{
+    std::lock_guard<std::mutex> lock(g_uncached_mutex);
+    for(UncachedBlock &b : g_uncached_blocks)
+        if(b.ptr == p)
+        {
+            b.in_use = false;
+            return true;
+        }
+    return false;
+}
+
+hipError_t alloc_views(uint8_t **out, size_t bytes, bool planar_layout, int device)
 {
     static const int forced = [] {
         const char *e = std::getenv("LFI_VIEWS_MEMORY");
@@ -118,7 +169,7 @@ hipError_t alloc_views(uint8_t **out, size_t bytes, bool planar_layout)
     }();
     const int kind = forced >= 0 ? forced : (planar_layout ? 1 : 0);
     if(kind == 1)
-        return hipExtMallocWithFlags(reinterpret_cast<void **>(out), bytes, hipDeviceMallocUncached);
+        return uncached_alloc(out, bytes, device);
     if(kind == 2)
         return hipExtMallocWithFlags(reinterpret_cast<void **>(out), bytes, hipDeviceMallocFinegrained);
     return hipMalloc(reinterpret_cast<void **>(out), bytes);
@@ -178,11 +229,13 @@ size_t in_plane_bytes(const lfi_ctx *c)
     return (size_t)c->width * c->in_rows * 4;
 }
 
-// planar view layout: bytes per row of a byte plane — a multiple of 16 so that every 8-byte store of blend_p3 is aligned and stays
-// inside its row whatever the width
+// planar view layout: bytes per row of a byte plane — a multiple of 128, so that every row starts on a cache line and every store
+// instruction of blend_p3 (16 lanes × 8 bytes) writes ONE whole line.  With W rounded up to 16 only, a width that is not a multiple of 128
+// put the rows at odd line phases and every store wrote two partial lines — into uncached memory: 1904 pixels 385 µs, 1936 pixels
+// 366 µs per config-2-like launch against 153 µs at 1920 (tools/plane_skew.py, profiles/r03_plane_skew.txt).
 int view_pitch(const lfi_ctx *c)
 {
-    return (c->width + 15) / 16 * 16;
+    return (c->width + 127) / 128 * 128;
 }
 
 size_t rgba_out_plane_bytes(const lfi_ctx *c)
@@ -314,7 +367,7 @@ void free_params(lfi_ctx *c)
 
 void free_views(lfi_ctx *c)
 {
-    if(c->own_views && c->views)
+    if(c->own_views && c->views && !uncached_release(c->views))
         (void)hipFree(c->views);
     c->views = nullptr;
     c->own_views = false;

@@ -271,7 +271,11 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     const int built_for = std::max(reach, c->planar_reach);
     const int padx = (built_for + 3) / 4 * 4;
     const int tiles_w = (c->width + 127) / 128 * 128;
-    const int pitch = (padx + 3 + tiles_w + built_for + 15) / 16 * 16; // + 3: the largest phase
+    int pitch = (padx + 3 + tiles_w + built_for + 15) / 16 * 16; // + 3: the largest phase
+#ifdef LFI_MEASUREMENT_BUILD // tools/plane_skew.py: do the 192 plane streams collide on HBM channels?  Extra bytes per plane row / per plane.
+    static const int extra_pitch = [] { const char *e = std::getenv("LFI_PLANAR_EXTRA_PITCH"); return e ? std::atoi(e) : 0; }();
+    pitch += extra_pitch / 16 * 16;
+#endif
     // blend_p3 / blend_stdx address a row as row·pitch with a 24-bit multiply, and a lane's byte inside its octet of images (8 images
     // × 3 planes, plus the row and the run) with 32 bits
     if(c->in_rows >= (1 << 24) || pitch >= (1 << 24) || (uint64_t)26 * c->in_rows * pitch >= (1ull << 32))

@@ -538,7 +538,7 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
         {
             free_views(ctx);
             ctx->views_bytes = out_plane_bytes(ctx) * V;
-            LFI_HIP(ctx, alloc_views(&ctx->views, ctx->views_bytes, ctx->out_layout == LFI_LAYOUT_PLANAR_RGB));
+            LFI_HIP(ctx, alloc_views(&ctx->views, ctx->views_bytes, ctx->out_layout == LFI_LAYOUT_PLANAR_RGB, ctx->device));
             ctx->own_views = true;
         }
     }
@@ -583,7 +583,7 @@ int lfi_set_output_layout(lfi_ctx *ctx, int layout)
     if(ctx->have_params)
     {
         ctx->views_bytes = out_plane_bytes(ctx) * ctx->views_n;
-        LFI_HIP(ctx, alloc_views(&ctx->views, ctx->views_bytes, ctx->out_layout == LFI_LAYOUT_PLANAR_RGB));
+        LFI_HIP(ctx, alloc_views(&ctx->views, ctx->views_bytes, ctx->out_layout == LFI_LAYOUT_PLANAR_RGB, ctx->device));
         ctx->own_views = true;
     }
     return LFI_OK;

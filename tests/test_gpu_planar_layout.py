@@ -176,6 +176,31 @@ def test_planar_layout_row_bands(world, cols, W, gpu, oracle_c):
     assert (got == want).all()
 
 
+def test_contexts_after_planar_view_contexts_render_correctly(gpu, oracle_c):
+    """Regression (round 3): the library's planar views live in uncached device memory.  Handed back to the HIP runtime with hipFree,
+    those address ranges were recycled for ordinary allocations, and contexts created after a few such cycles rendered garbage (inputs,
+    parameters or RGBA views on a range that had been uncached).  Released blocks now stay in a process-wide free list.  The sequence
+    that exposed it: a few contexts that switch to the planar layout and are closed, then fresh contexts of other shapes."""
+    for cols, W in [(8, 203), (11, 131), (8, 200)]:
+        rows = cols
+        H, V = 96, 64 if cols == 8 else 40
+        hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.1, 0.0, 3.0, 1.783, V)
+        lf = oracle_c.synthetic_lf(cols * rows, W, H, SEED)
+        m16 = oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, model=oracle_c.TEN_M16, threads=8)
+        for rep in range(3):
+            ctx = _ctx(gpu, cols, rows, W, H, hp, layout="rgba")
+            for variant in ("persist_m2_nt", "auto"):
+                ctx.set_variant("TEN_WM", variant)
+                ctx.render("TEN_WM")
+                ctx.sync()
+                assert np.abs(ctx.download_views().astype(int) - m16.astype(int)).max() <= TEN_TOL_LSB, (cols, W, rep, variant)
+            ctx.set_output_layout("planar")
+            ctx.render("TEN_WM")
+            ctx.sync()
+            assert np.abs(ctx.download_views().astype(int) - m16.astype(int)).max() <= TEN_TOL_LSB, (cols, W, rep, "planar")
+            ctx.close()
+
+
 def test_planar_layout_quilt_and_attached_views(gpu):
     import torch
     cols = rows = 3
