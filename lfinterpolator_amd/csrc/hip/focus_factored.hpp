@@ -969,15 +969,27 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
 // dispersion per candidate = nine samples of E, or K where the pair is flagged on either axis; first strict minimum → map 0.
 // Blocks of 4 rows × 64·PPL pixels, a lane owns PPL ∈ {1, 2} adjacent pixels; PPL = 2 reads both pixels' samples with one
 // dword load and needs an even radius_x (the E columns x + rx ± rx of an even x are then dword aligned) — the reference always
-// produces one (src/interpolator.cu:143-146).  Every sample is scalar plane base + per-lane tap offset.  Row-major block
-// order, consecutive blocks on different XCDs: the flagged rows sit at the top of the image and the flagged columns at its
-// left, so neither row bands nor column stripes per XCD would spread the waves that also read K evenly.
+// produces one (src/interpolator.cu:143-146).  Every sample is scalar plane base + per-lane tap offset.
 template <int PPL>
-__global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const FocusWork w)
+__global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const FocusWork w, const int striped)
 {
     const int W = a.width, H = a.height;
     const uint32_t blocks_x = uint32_t(W + 64 * PPL - 1) / uint32_t(64 * PPL);
-    const uint32_t bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
+    uint32_t bx, by;
+    if(striped)
+    {
+        // round 3: one vertical stripe of blocks per XCD, walked top to bottom.  A row of E is sampled by three pixel rows 2·ry apart; in
+        // row-major order over the whole width those meet in no L2 (2·ry rows × 32 candidates × the image width: 11 MB at 4K) and E came
+        // from the fabric three times (TCC hit rate 4 %, profiles/r02_pmc_focus_range_summary.txt); an eighth of the width fits.
+        uint32_t in;
+        if(!stripe_map(blockIdx.x, blocks_x, uint32_t(H + 3) / 4u, 1u, bx, by, in))
+            return;
+    }
+    else
+    {
+        bx = blockIdx.x % blocks_x;
+        by = blockIdx.x / blocks_x;
+    }
     const int x = (int(bx) * 64 + int(threadIdx.x & 63)) * PPL;
     const int y = __builtin_amdgcn_readfirstlane(int(by) * 4 + int(threadIdx.x >> 6));
     if(y >= H) // wave-uniform

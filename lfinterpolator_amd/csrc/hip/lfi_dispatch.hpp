@@ -365,7 +365,12 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
 {
     const int tiles_x = (a_in.width + lfi::P3_TPX - 1) / lfi::P3_TPX;
     const int n_tiles = tiles_x * a_in.out_rows;
+#ifdef LFI_MEASUREMENT_BUILD // LFI_P3_WGS = workgroups per CU in the grid (1 or 2): does a launch scale with the waves per CU?
+    static const int wgs_env = [] { const char *e = std::getenv("LFI_P3_WGS"); return e ? std::atoi(e) : 2; }();
+    const dim3 grid(std::min(n_tiles, wgs_env * cu_count_of(c))), block(256);
+#else
     const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+#endif
     const int nch = (a_in.k_pad + lfi::P3_KC - 1) / lfi::P3_KC;
     note_kernel(c, "blend_p3<TEN_WM>");
 #ifdef LFI_MEASUREMENT_BUILD

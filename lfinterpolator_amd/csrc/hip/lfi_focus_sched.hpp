@@ -139,11 +139,13 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     {
         // two pixels per lane need dword-aligned sample pairs: even radius_x (the reference's is)
         const int ppl = (rx % 2 == 0 && W >= 2) ? 2 : 1;
-        const uint32_t nblocks = uint32_t((W + 64 * ppl - 1) / (64 * ppl)) * uint32_t((H + 3) / 4);
+        const uint32_t blocks_x = uint32_t((W + 64 * ppl - 1) / (64 * ppl)), blocks_y = uint32_t((H + 3) / 4);
+        const int striped = blocks_x >= 8;
+        const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(blocks_x, blocks_y, 1u) : blocks_x * blocks_y;
         if(ppl == 2)
-            hipLaunchKernelGGL(lfi::focus_pick<2>, dim3(nblocks), dim3(256), 0, st, a, w);
+            hipLaunchKernelGGL(lfi::focus_pick<2>, dim3(nblocks), dim3(256), 0, st, a, w, striped);
         else
-            hipLaunchKernelGGL(lfi::focus_pick<1>, dim3(nblocks), dim3(256), 0, st, a, w);
+            hipLaunchKernelGGL(lfi::focus_pick<1>, dim3(nblocks), dim3(256), 0, st, a, w, striped);
     }
     LFI_HIP(ctx, hipGetLastError());
     *done = true;
