@@ -176,6 +176,45 @@ def test_planar_layout_row_bands(world, cols, W, gpu, oracle_c):
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("V,W,H", [(129, 200, 9), (200, 131, 7), (256, 384, 5)])
+def test_planar_layout_three_and_more_view_passes(V, W, H, gpu, oracle_c):
+    """256 views from 64 images (BASELINE config 4 on one GPU): three or more 64-view passes per LDS-resident tile in blend_p3.  Within
+    one LSB of the oracle's M16, identical to the RGBA layout's kernel, both sweep directions, a view range that starts inside a pass,
+    and a row band."""
+    cols = rows = 8
+    hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.15, 0.0, 3.0, 1.783, V)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, SEED)
+    m16 = oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, model=oracle_c.TEN_M16, threads=8)
+    ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    for sweep in range(2):
+        ctx.render("TEN_WM")
+        ctx.sync()
+        assert ctx.last_kernel_name() == "blend_p3<TEN_WM>"
+        got = ctx.download_views()
+        assert np.abs(got.astype(int) - m16.astype(int)).max() <= TEN_TOL_LSB, sweep
+    ctx.render("TEN_WM", v0=5, v1=V - 3)            # 3 or 4 passes from an odd first view
+    ctx.sync()
+    assert (ctx.download_views(5, V - 3) == got[5:V - 3]).all()
+    ctx.set_output_layout("rgba")
+    ctx.render("TEN_WM")
+    ctx.sync()
+    assert (ctx.download_views() == got).all()
+    ctx.close()
+    if H >= 7:
+        band = (2, H - 2)
+        in_rows = gpu.input_rows(band, hp.focused_offsets, H)
+        ctx = gpu.Context(0)
+        ctx.set_grid(cols, rows, W, H)
+        ctx.set_row_window(band[0], band[1], in_rows[0], in_rows[1])
+        ctx.upload_grid(lf)
+        ctx.set_params(hp)
+        ctx.set_output_layout("planar")
+        ctx.render("TEN_WM")
+        ctx.sync()
+        assert (ctx.download_views()[:, band[0]:band[1]] == got[:, band[0]:band[1]]).all()
+        ctx.close()
+
+
 def test_contexts_after_planar_view_contexts_render_correctly(gpu, oracle_c):
     """Regression (round 3): the library's planar views live in uncached device memory.  Handed back to the HIP runtime with hipFree,
     those address ranges were recycled for ordinary allocations, and contexts created after a few such cycles rendered garbage (inputs,
