@@ -11,6 +11,7 @@
 #include "blend_planar.hpp"
 #include "blend_p3.hpp"
 #include "blend_stdx.hpp"
+#include "blend_stdxa.hpp"
 #include "blend_wave.hpp"
 
 namespace {
@@ -109,6 +110,29 @@ void launch_wave(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 // planar copy and the weights for it, else the exact-fp32 MFMA kernels
 void launch_std_filtered(const lfi_ctx *c, const KernelArgs &a_in, bool all_focus)
 {
+    if(all_focus && c->weights_scalable && c->weights_sum_ok && !a_in.prequant && a_in.k_pad <= 4 * 64)
+    {
+        // all-focus: blend_stdxa — the band method on the per-pixel gather pipeline (RGBA planes; no derived copy); one launch per 64 views
+        const int tiles_x = (a_in.width + 127) / 128;
+        const int n_tiles = tiles_x * a_in.out_rows;
+        const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
+        const int nch = (a_in.k_pad + 63) / 64;
+        note_kernel(c, "blend_stdxa<STD,allfocus>");
+        for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 64)
+        {
+            KernelArgs a = a_in;
+            a.v0 = v0;
+            a.v1 = std::min(v0 + 64, a_in.v1);
+            switch(nch)
+            {
+                case 1: hipLaunchKernelGGL((lfi::blend_stdxa<true, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
+                case 2: hipLaunchKernelGGL((lfi::blend_stdxa<true, 2>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
+                case 3: hipLaunchKernelGGL((lfi::blend_stdxa<true, 3>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
+                default: hipLaunchKernelGGL((lfi::blend_stdxa<true, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
+            }
+        }
+        return;
+    }
     if(!a_in.planar || all_focus || a_in.k_pad > 4 * lfi::P3_KC)
     {
         launch_wave<true, 2, true>(c, a_in, all_focus);

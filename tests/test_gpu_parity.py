@@ -596,6 +596,84 @@ def test_std_band_method_over_several_chunks(cols, rows, W, H, V, kind, gpu, ora
         ctx.close()
 
 
+@pytest.mark.parametrize("cols,rows,W,H,V,kind", [
+    (8, 8, 200, 6, 64, "random"),             # one chunk: no C units at all
+    (3, 3, 97, 5, 5, "random"),               # nine images: one short chunk, ragged width, five views
+    (9, 9, 260, 5, 64, "random"),             # two chunks
+    (12, 12, 131, 4, 37, "random"),           # three chunks; ragged width
+    (15, 15, 300, 4, 64, "random"),           # four chunks (BASELINE config 5)
+    (15, 15, 140, 3, 70, "random"),           # two launches of views (64 + 6)
+    (13, 10, 257, 3, 64, "ties_everywhere"),  # every sum an exact tie: the queue overflows, the spill path computes from global memory
+    (11, 11, 260, 4, 48, "sum_1p999"),        # sums up to 510
+    (15, 15, 200, 3, 33, "tiny_weights"),
+])
+def test_all_focus_std_band_method(cols, rows, W, H, V, kind, gpu, oracle_c):
+    """All-focus STD goes through blend_stdxa: fp16-MFMA sums of the per-pixel gathered samples over all chunks, the sums inside the rounding
+    band recomputed with the chain from a second gather of the tile.  Bit-exact against the oracle on random inputs and on inputs built to
+    sit on the band, with noisy and blocky focus maps, the analytic band, a view range, a row band and the planar view layout."""
+    n = cols * rows
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.05, 0.3, 3.0, 1.783, V)
+    rng = np.random.default_rng(n + V)
+    lf = oracle_c.synthetic_lf(n, W, H, 9 + n)
+    if kind != "random":
+        w = np.zeros((V, n), np.float32)
+        if kind == "ties_everywhere":
+            for v in range(V):
+                a_, b_ = rng.choice(n, 2, replace=False)
+                w[v, a_] = w[v, b_] = 0.5
+            lf[..., :3] = (lf[..., :3] // 2) * 2
+            lf[::2, :, :, :3] += 1
+        elif kind == "sum_1p999":
+            w = np.abs(rng.standard_normal((V, n))).astype(np.float32)
+            w *= 1.99 / w.sum(1, keepdims=True)
+        else:
+            w = (rng.random((V, n)) * 3e-5).astype(np.float32)
+            w[:, n // 2] = 0.75
+        hp.weights = _f16_bits(w)
+    lf[..., 3] = 255
+    levels = np.repeat(np.repeat(rng.integers(0, 256, size=((H + 1) // 2, (W + 15) // 16)), 2, axis=0), 16, axis=1)[:H, :W]
+    levels[:, W // 2:] = rng.integers(0, 256, size=(H, W - W // 2))        # the right half: a noise map
+    m = np.repeat(levels[..., None].astype(np.uint8), 4, axis=-1)
+    m[..., 3] = 255
+    want = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, all_focus=True, map_plane=m, focus=hp.focus, rng=hp.range, threads=8)
+    for flags in (0, gpu.LFI_FLAG_STD_ANALYTIC_BAND):
+        ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf, flags=flags)
+        ctx.upload_map(1, m)                   # Standard::process<true> reads map 1 (src/kernels.cu:326)
+        ctx.render("STD", all_focus=True)
+        ctx.sync()
+        assert ctx.last_kernel_name() == "blend_stdxa<STD,allfocus>"
+        got = ctx.download_views()
+        assert (got == want).all(), (kind, flags, int((got != want).sum()))
+        if flags == 0:
+            v0, v1 = V // 3, V // 3 + min(20, V - V // 3)
+            ctx.render("STD", all_focus=True, v0=v0, v1=v1)
+            ctx.sync()
+            assert (ctx.download_views(v0, v1) == want[v0:v1]).all(), (kind, "view range")
+            ctx.set_variant("STD", "wave_m2_nt")          # the exact-fp32 kernel agrees
+            ctx.render("STD", all_focus=True)
+            ctx.sync()
+            assert ctx.last_kernel_name() == "blend_persist<STD,allfocus>" and (ctx.download_views() == want).all()
+            ctx.set_variant("STD", "auto")
+            ctx.set_output_layout("planar")               # RGBA scratch + conversion
+            ctx.render("STD", all_focus=True)
+            ctx.sync()
+            assert (ctx.download_views() == want).all(), (kind, "planar layout")
+        ctx.close()
+    if H >= 4:
+        band = (1, H - 1)
+        in_rows = gpu.input_rows_all_focus(band, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, H)
+        ctx = gpu.Context(0)
+        ctx.set_grid(cols, rows, W, H)
+        ctx.set_row_window(band[0], band[1], in_rows[0], in_rows[1])
+        ctx.upload_grid(lf)
+        ctx.set_params(hp)
+        ctx.upload_map(1, m)
+        ctx.render("STD", all_focus=True)
+        ctx.sync()
+        assert (ctx.download_views()[:, band[0]:band[1]] == want[:, band[0]:band[1]]).all(), (kind, "row band")
+        ctx.close()
+
+
 def test_std_analytic_band_flag(gpu, oracle_c):
     """LFI_FLAG_STD_ANALYTIC_BAND sizes the band of blend_planar<STDF> with the analytic accumulation bound (a whole ulp per addend)
     instead of the measured one: same kernel, same bytes, more sums recomputed — bit-exact like the default."""
