@@ -4,7 +4,8 @@
 // Rounds 1–2 ran every all-focus STD render on the exact-fp32 matrix instruction (7.5 ms at config 5, 0.61 of the fp32 peak).  Here, as in
 // blend_stdx: fp16 MFMA sums over all chunks of images (descending), the band test and the RGBA stores of the rounded bytes after the last
 // one (chunk 0), the sums inside the band queued per wave (two per lane) and recomputed with the chain itself — chunk 0 from the buffer
-// still resident, chunks 1 … from a SECOND gather of the same tile (cache traffic) — then byte patches.  What differs from blend_stdx:
+// still resident, chunk 1 from the buffer the previous unit left, chunks 2 … from a SECOND gather of the same tile (cache traffic) — then
+// byte patches.  What differs from blend_stdx:
 //   * the pipeline is blend_persist<…, ALLFOCUS>'s: per pixel and image one 4-byte LDS-DMA gather at (int)fma(f, offset, coord) clamped
 //     (src/kernels.cu:78-82, :125), f decoded from the focus map; two 32 KB pixel buffers [image][128 pixels] of RGBA dwords and two 8 KB
 //     weight buffers per workgroup, one unit ahead; wave = 32 pixels × 64 views on v_mfma_f32_32x32x16_f16;
@@ -167,7 +168,10 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
         const bool last_of_tile = u == NU - 1;
         const int nt = last_of_tile ? t + G : t;
         const bool have_next = nt < n_tiles;
-        if(have_next)
+        // The unit after MC(0) is C(1), and chunk 1 of this very tile is what the unit before MC(0), M(1), left in the other pair of buffers
+        // (pixels and weights): nothing is fetched for it.  (blend_stdx's ring of three has overwritten that buffer by then.)
+        constexpr bool next_is_resident = is_mc && NCH >= 2;
+        if(have_next && !next_is_resident)
             issue(nt, unit_chunk(last_of_tile ? 0 : u + 1), buf ^ 1);
         prev_stores = 0;
 
