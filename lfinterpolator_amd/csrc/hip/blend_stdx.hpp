@@ -14,8 +14,8 @@
 //                    C(1) … C(NCH−1)   the same chunks fetched AGAIN through the same LDS-DMA ring (they left this workgroup's L2 /
 //                                      the Infinity Cache microseconds ago), chain continued in ascending image order; after the last
 //                                      one the chain's bytes are patched over the rounded ones (byte stores by the wave that wrote the
-//                                      dwords: same-wave stores to one address retire in order).  The C units of a tile run
-//                                      INTERLEAVED with the M units of the next tile (see the unit sequence below).
+//                                      dwords: same-wave stores to one address retire in order).  C(1) fetches nothing: chunk 1 is
+//                                      still in the buffer M(1) left (sx_buffer below).
 //
 // so HBM sees the inputs once; the second fetch is cache traffic.  Pipeline (persistent workgroups, ring of three buffers two units
 // ahead, one barrier and one hand-counted vmcnt wait per unit), operand maps, DMA addressing: blend_p3.hpp, four waves of 16 views.
@@ -37,13 +37,25 @@
 namespace lfi {
 
 constexpr int SX_QCAP = 128; // queued (pixel, view, channel) sums per wave and tile: two per lane
-// measurement builds only (hipcc -DLFI_SX_ABL=n, tools/stdx_ablate.sh): 1 = no chain arithmetic (the C units still fetch), 2 = no C units at
-// all, 3 = 2 and no band test (plain rounding).  Outputs of n != 0 are wrong by construction.
+// measurement builds only (hipcc -DLFI_SX_ABL=1, tools/stdx_ablate.sh): no chain arithmetic (the C units still fetch); the output is wrong
+// by construction.  (Rounds of ablations without the C units or the band test: profiles/r03_stdx_ablation_*.txt, an earlier form of the kernel.)
 #ifndef LFI_SX_ABL
 #define LFI_SX_ABL 0
 #endif
 
-template <bool NT_STORE, int NCH, bool ILV = false>
+// The ring buffer of unit `sl` (0 … 2·NCH − 2: M(NCH−1) … M(1), MC(0), C(1) … C(NCH−1)) of a workgroup's j-th tile.  Fetches run two units
+// ahead, each into the buffer of the unit that finished last — except that C(1) fetches NOTHING: chunk 1 of the tile is what M(1), two units
+// earlier, left in its buffer, which is therefore kept until C(1) is done (the all-focus kernel's observation, blend_stdxa.hpp, carried
+// over to a ring of three).  Written out, the assignment repeats with period two tiles, the second tile mirrored (2 − buffer):
+template <int NCH>
+__host__ __device__ constexpr int sx_buffer(const int j, const int sl)
+{
+    constexpr int t2[3] = {0, 1, 0}, t3[5] = {0, 1, 2, 1, 0}, t4[7] = {0, 1, 2, 0, 2, 1, 0};
+    const int v = NCH == 2 ? t2[sl] : (NCH == 3 ? t3[sl] : t4[sl]);
+    return (j & 1) ? 2 - v : v;
+}
+
+template <bool NT_STORE, int NCH>
 __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const int tiles_x, const int n_tiles, const int reverse)
 {
     static_assert(NCH >= 2 && NCH <= 4, "two to four chunks of 64 images");
@@ -243,19 +255,14 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
     // (unsigned char)__float2int_rn(sum) (uch4, src/kernels.cu:301-310): + 2^23 rounds to nearest-even and leaves the integer in the low bits
     auto byte_of = [](const float s15) { return __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; };
 
-    // ---- the unit sequence of this workgroup ---------------------------------------------------------------------------------------
-    // Tiles t0, t0 + G, … (T of them).  Iteration j runs the MFMA units of tile j INTERLEAVED with the chain units of tile j − 1:
-    //      slot 0: M(NCH−1)   1: C'(1)   2: M(NCH−2)   3: C'(2)   …   2(NCH−2): M(1)   2NCH−3: C'(NCH−1)   2NCH−2: MC(0)
-    // (C' = a C unit of the previous tile; iteration 0 has no C' units, iteration T only C' units).  A C unit computes for a microsecond;
-    // three of them in a row left the fetches issued during them — the next tile's first chunks, from HBM — two short units of lead
-    // (0.4–0.6 ms of a config-5 launch, tools/stdx_ablate.sh).  Alternating, every fetch has an MFMA unit's time to land.
-    // ILV = false: the C units follow their own tile's MC unit (slots 0 … NCH−2: M, NCH−1: MC, NCH … 2NCH−2: C(1) … C(NCH−1)).
+    // ---- the unit sequence of this workgroup: tiles t0, t0 + G, … (T of them), 2·NCH − 1 units each ------------------------------------
+    // (The C units of a tile interleaved with the next tile's M units, so that no fetch is issued with two short units of lead, measured
+    // SLOWER — 3.05 against 2.93 ms at config 5, profiles/r03_stdx_interleave_ab.txt: the second fetch is traffic, not latency.)
     const int T = (n_tiles - 1 - t0) / G + 1;
-    auto slot_is_c = [](const int sl) { return ILV ? (sl & 1) != 0 : sl >= NCH; };
-    auto slot_valid = [&](const int j, const int sl) { return slot_is_c(sl) ? (LFI_SX_ABL < 2 && (ILV ? j >= 1 : j < T)) : j < T; };
-    auto slot_chunk = [](const int sl) { return ILV ? ((sl & 1) ? (sl + 1) / 2 : NCH - 1 - sl / 2) : (sl < NCH ? NCH - 1 - sl : sl - NCH + 1); };
-    auto slot_tile = [&](const int j, const int sl) { return t0 + ((ILV && slot_is_c(sl)) ? j - 1 : j) * G; };
-    int ij = 0, isl = 0; // issue cursor: the next unit to fetch; past the end when ij > T
+    auto slot_valid = [&](const int j, const int sl) { return j < T && sl < NU; };
+    auto slot_chunk = [](const int sl) { return sl < NCH ? NCH - 1 - sl : sl - NCH + 1; };
+    auto slot_fetches = [](const int sl) { return sl != NCH; }; // C(1) reads the buffer M(1) left
+    int ij = 0, isl = 0; // issue cursor: the next unit to fetch; past the end when ij ≥ T
     auto advance_issue = [&] {
         do
         {
@@ -264,23 +271,24 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                 isl = 0;
                 ij++;
             }
-        } while(ij <= T && !slot_valid(ij, isl));
+        } while(ij < T && !slot_valid(ij, isl));
     };
-    auto issue_cursor = [&](const int buf, const Pieces &pc) { return issue(slot_tile(ij, isl), slot_chunk(isl), buf, pc); };
+    // fetch the unit under the cursor (if it fetches at all); returns this wave's DMA instructions
+    auto issue_cursor = [&](const Pieces &pc) { return slot_fetches(isl) ? issue(t0 + ij * G, slot_chunk(isl), sx_buffer<NCH>(ij, isl), pc) : 0; };
     Pieces pc = lookup(slot_chunk(0));
-    issue_cursor(0, pc);
+    issue_cursor(pc);
     advance_issue();
-    bool have1 = ij <= T; // a unit after the current one exists (and is in flight)
+    bool have1 = ij < T; // a unit after the current one exists (and is in flight, if it fetches)
     int nd1 = 0;
     if(have1)
     {
         pc = lookup(slot_chunk(isl));
-        nd1 = issue_cursor(1, pc);
+        nd1 = issue_cursor(pc);
         advance_issue();
     }
-    if(ij <= T)
+    if(ij < T)
         pc = lookup(slot_chunk(isl));
-    int cj = 0, buf = 0; // compute cursor: iteration (the slot is the compile-time argument of `unit`)
+    int cj = 0; // compute cursor: the tile (the unit is the compile-time argument of `unit`)
     int st1 = 0, st2 = 0;
     const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw0, 16)); // ≤ 0: this wave only helps with the DMA
     // the queued sums of the tile whose MC unit ran last: two per lane
@@ -290,10 +298,11 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
 
     auto unit = [&](auto sl_tag) -> bool {
         constexpr int sl = decltype(sl_tag)::value;
-        constexpr bool is_c = ILV ? (sl & 1) != 0 : sl >= NCH;
-        constexpr bool is_mc = ILV ? sl == NU - 1 : sl == NCH - 1;
-        constexpr int cc = ILV ? (is_c ? (sl + 1) / 2 : NCH - 1 - sl / 2) : (sl < NCH ? NCH - 1 - sl : sl - NCH + 1);
-        constexpr bool is_last_c = ILV ? sl == NU - 2 : sl == NU - 1;
+        constexpr bool is_c = sl >= NCH;
+        constexpr bool is_mc = sl == NCH - 1;
+        constexpr int cc = sl < NCH ? NCH - 1 - sl : sl - NCH + 1;
+        constexpr bool is_last_c = sl == NU - 1;
+        const int buf = sx_buffer<NCH>(cj, sl);
         const int allowed = st2 + (have1 ? nd1 : 0) + st1;
         switch(min(allowed, 63) >> 2)
         {
@@ -316,13 +325,13 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
         }
         __builtin_amdgcn_s_barrier(); // everybody's pieces of this unit have landed; everybody is done with the previous unit's buffer
         asm volatile("" ::: "memory");
-        const bool have2 = have1 && ij <= T;
+        const bool have2 = have1 && ij < T;
         int nd2 = 0;
         if(have2)
         {
-            nd2 = issue_cursor(buf == 0 ? 2 : buf - 1, pc); // (buf + 2) % 3: the buffer the previous unit used
+            nd2 = issue_cursor(pc); // into the buffer of a unit that has finished (sx_buffer)
             advance_issue();
-            if(ij <= T)
+            if(ij < T)
                 pc = lookup(slot_chunk(isl)); // for the unit after that: off the critical path of the next barrier
         }
         const int kc = min(P3_KC, a.k_pad - P3_KC * cc);
@@ -331,7 +340,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
         if(nvalid > 0)
         {
             int ty, x0;
-            tile_xy(slot_tile(cj, sl), ty, x0);
+            tile_xy(t0 + cj * G, ty, x0);
             if constexpr(!is_c)
             {
                 half8 wk[2] = {wreg[2 * cc], wreg[2 * cc + 1]};
@@ -366,8 +375,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                             const float dist = v - (t - 16384.0f);
                             const float pow2 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v + bmax_acc) & 0x7f800000u);
                             const float inside = __builtin_fmaf(-chain_acc, pow2, base_acc);
-                            if constexpr(LFI_SX_ABL < 3)
-                                mask[i] |= __builtin_fabsf(dist) > inside ? 1u << (3 * b + ch) : 0u;
+                            mask[i] |= __builtin_fabsf(dist) > inside ? 1u << (3 * b + ch) : 0u;
                             bits[ch] = __builtin_bit_cast(uint32_t, t);
                         }
                         const uint32_t rg = __builtin_amdgcn_perm(bits[1], bits[0], 0x0c0c0400u); // [R, G, 0, 0]
@@ -476,7 +484,6 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
         }
         if(!have1)
             return false;
-        buf = buf == 2 ? 0 : buf + 1;
         have1 = have2;
         nd1 = nd2;
         return true;

@@ -153,11 +153,7 @@ void launch_std_filtered(const lfi_ctx *c, const KernelArgs &a_in, bool all_focu
             KernelArgs a = a_in;
             a.v0 = v0;
             a.v1 = std::min(v0 + 64, a_in.v1);
-#ifdef LFI_SX_ILV // measurement builds: the C units of a tile interleaved with the next tile's M units (blend_stdx.hpp)
-#define LFI_SX_LAUNCH(N) hipLaunchKernelGGL((lfi::blend_stdx<true, N, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse)
-#else
 #define LFI_SX_LAUNCH(N) hipLaunchKernelGGL((lfi::blend_stdx<true, N>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse)
-#endif
             switch(nch)
             {
                 case 2: LFI_SX_LAUNCH(2); break;
