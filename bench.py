@@ -232,9 +232,9 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
             k = ctx.last_kernel_name()
             ms_e = timed(ctx, lambda: (ctx.focus_map(), ctx.render(method, all_focus=True)), max(2, iters // 4), warm=1)
             key = "config5_allfocus_" + method.lower()
-            out[key + "_render"] = entry(c5, ms_r, 64, k, "all-focus render from a resident focus map (structured light field)", flops_bound=(method == "STD"))
+            out[key + "_render"] = entry(c5, ms_r, 64, k, "all-focus render from a resident focus map (structured light field)")
             out[key + "_end_to_end"] = entry(c5, ms_e, 64, "focus map + " + k, "lfi_focus_map + all-focus render per iteration (-r 0.17)",
-                                             in_bytes_extra=map_in + map_io, flops_bound=(method == "STD"))
+                                             in_bytes_extra=map_in + map_io)
         ctx.set_variant("STD", "vfma")
         ms_r = timed(ctx, lambda: ctx.render("STD", all_focus=True), 2, warm=1, rounds=2)
         out["config5_allfocus_std_nontensor"] = entry(c5, ms_r, 64, ctx.last_kernel_name(), "all-focus render by the non-tensor wavefront kernel", flops_bound=True)
