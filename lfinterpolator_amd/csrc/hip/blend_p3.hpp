@@ -285,35 +285,46 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
                          : "s"(k255), "s"(two));
 #undef h
         }
+        // 16 bytes per lane and store (round 3): the MFMA leaves a lane 8 pixels of four views; neighbouring lanes (n, n ^ 1) swap — the even
+        // lane takes both lanes' pixels of view i0, the odd lane both lanes' pixels of view i0 + 1 (two DPP moves per channel) — so that one
+        // dwordx4 store per lane replaces two dwordx2 stores: half the store instructions, still whole 128-byte lines (eight lanes × 16
+        // bytes per view and plane row).  The 8-byte stores were issue-bound where a launch writes more than it reads: 256 views from 64 images,
+        // BASELINE config 4 on one GPU (profiles/r03_notes.md §10).
         // wave-uniform 64-bit base per store + one 32-bit per-lane byte offset (12 planes < 4 GB)
         uint8_t *ubase = a.views + ((size_t)vw * 3 * a.out_rows + ty) * a.views_pitch + x0;
-        const uint32_t lane_off = uint32_t(12 * kg) * plane_b + uint32_t(8 * n);
-        const bool x_ok = x0 + 8 * n < a.views_pitch; // the pitch is a multiple of 16 ≥ W: a whole 8-byte store stays inside the row
+        const bool odd = n & 1;
+        const uint32_t lane_off = uint32_t(12 * kg + (odd ? 3 : 0)) * plane_b + uint32_t(8 * (n & ~1));
+        const bool x_ok = x0 + 8 * (n & ~1) < a.views_pitch; // the pitch is a multiple of 128 ≥ W: a whole 16-byte store stays inside the row
         int n_st = 0;
 #pragma unroll
-        for(int i = 0; i < 4; i++)
+        for(int ip = 0; ip < 2; ip++)
         {
-            if(i >= nvalid) // wave-uniform; otherwise lane (n = 0, kg = 0) is active and every store below is issued
+            const int i0 = 2 * ip;
+            if(i0 >= nvalid) // wave-uniform; otherwise lane (n = 0, kg = 0) is active and every store below is issued
                 continue;
 #pragma unroll
             for(int ch = 0; ch < 3; ch++)
             {
-                const uint32_t *q = &hq[(i * 3 + ch) * 4];
-                const u32x2 px8 = {__builtin_amdgcn_perm(q[1], q[0], 0x06040200u),  // pixels 8n … 8n+3
-                                   __builtin_amdgcn_perm(q[3], q[2], 0x06040200u)}; // pixels 8n+4 … 8n+7
-                u32x2 *out = reinterpret_cast<u32x2 *>(ubase + (size_t)(3 * i + ch) * plane_b + lane_off);
+                const uint32_t *q0 = &hq[(i0 * 3 + ch) * 4], *q1 = &hq[((i0 + 1) * 3 + ch) * 4];
+                const uint32_t a0 = __builtin_amdgcn_perm(q0[1], q0[0], 0x06040200u), a1 = __builtin_amdgcn_perm(q0[3], q0[2], 0x06040200u); // view i0
+                const uint32_t b0 = __builtin_amdgcn_perm(q1[1], q1[0], 0x06040200u), b1 = __builtin_amdgcn_perm(q1[3], q1[2], 0x06040200u); // view i0 + 1
+                // what the partner needs: the even lane gives away its pixels of view i0 + 1, the odd lane its pixels of view i0
+                const uint32_t r0 = uint32_t(__builtin_amdgcn_mov_dpp(int(odd ? a0 : b0), 0xB1, 0xf, 0xf, false)); // quad_perm [1, 0, 3, 2]
+                const uint32_t r1 = uint32_t(__builtin_amdgcn_mov_dpp(int(odd ? a1 : b1), 0xB1, 0xf, 0xf, false));
+                const u32x4 px16 = {odd ? r0 : a0, odd ? r1 : a1, odd ? b0 : r0, odd ? b1 : r1}; // 16 pixels from 8(n & ~1) of this lane's view
+                u32x4 *out = reinterpret_cast<u32x4 *>(ubase + (size_t)(3 * i0 + ch) * plane_b + lane_off);
                 if constexpr(ABL == 3)
                 {
-                    asm volatile("" ::"v"(px8), "v"(out));
+                    asm volatile("" ::"v"(px16), "v"(out));
                     continue;
                 }
                 n_st++;
-                if(x_ok && 4 * kg + i < nvalid)
+                if(x_ok && 4 * kg + i0 + (odd ? 1 : 0) < nvalid)
                 {
                     if constexpr(NT_STORE)
-                        __builtin_nontemporal_store(px8, out);
+                        __builtin_nontemporal_store(px16, out);
                     else
-                        *out = px8;
+                        *out = px16;
                 }
             }
         }
