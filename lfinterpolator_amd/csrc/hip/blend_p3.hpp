@@ -65,18 +65,22 @@ __device__ __forceinline__ void p3_for_each_chunk(F &&f)
 }
 
 // planar views: plane (view, channel) at ((view·3 + channel)·rows)·pitch, pixel x of row y at y·pitch + x
-// view_passes > 1 (more than 64 views; NCH == 1 only — the host splits other launches): the tile stays in LDS for every pass, the
-// weight fragments of the next pass are fetched while the current one computes.
+// view_passes > 1 (more than 64 views; NCH == 1 only — the host splits other launches): the tile stays in LDS for every pass.  MP =
+// the most passes a launch may have (1 or 4): the weight fragments of ALL passes stay in registers (8 per pass).  Round 2 fetched the
+// next pass's fragments while the current one computed; the compiler, which cannot count the predicated stores issued after those
+// loads, waited for them with s_waitcnt vmcnt(0) — a drain of the wave's stores AND its LDS-DMA prefetch once per pass
+// (profiles/r03_notes.md §11: config 4 whole 1.90 → 1.69 ms).
 // ABL (measurement builds only, LFI_P3_ABLATE): 0 = the kernel; 1 = no k-loop (DMA + barriers + stores of zeros); 2 = no DMA (the
 // k-loop runs on whatever LDS holds); 3 = no stores.  Outputs of ABL != 0 are garbage by construction.
 // VG: groups of 16 views per wave.  1: four waves per workgroup, two waves per SIMD (memory-bound launches: one chunk of images).
 // 2: TWO waves per workgroup, 32 views each — the pixel operand of a block (LDS read + v_perm) is built once for two MFMAs, and the
 // kernel needs more than 256 registers (192 accumulators), which pins one wave to each SIMD: two workgroups per CU as before, each
 // wave alone on its SIMD.  For launches of several chunks, where the k-loop (not the DMA) sets the pace with four waves.
-template <bool NT_STORE, int NCH, int ABL = 0, int VG = 1>
+template <bool NT_STORE, int NCH, int ABL = 0, int VG = 1, int MP = 1>
 __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes, const int reverse)
 {
     static_assert(VG == 1 || VG == 2, "16 or 32 views per wave");
+    static_assert(MP == 1 || NCH == 1, "several view passes: one chunk of images only");
     constexpr int NW = 4 / VG;  // waves per workgroup
     constexpr int OPW = 8 / NW; // octets of a chunk (and channel) each wave fetches
     __shared__ __attribute__((aligned(16))) uint8_t lds[3 * P3_BUF_B + LFI_MAX_IMAGES * 8];
@@ -112,13 +116,28 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
     };
     half8 wreg[VG][2 * NCH];
     load_weights(0, wreg);
+    half8 wmore[MP > 1 ? MP - 1 : 1][VG][2 * NCH]; // passes 1 … MP − 1
+    if constexpr(MP > 1)
+    {
+#pragma unroll
+        for(int p = 1; p < MP; p++)
+            load_weights(p < view_passes ? p : 0, wmore[p - 1]); // (a pass the launch does not have: any valid rows, never used)
+    }
     // the loads above are the only vector loads the compiler knows about: make it wait for them HERE, before any LDS-DMA is in
     // flight, instead of with a vmcnt(0) in front of the first MFMA (which would also drain the pipeline's first three tiles)
 #pragma unroll
     for(int vg = 0; vg < VG; vg++)
 #pragma unroll
         for(int s = 0; s < 2 * NCH; s++)
+        {
             asm volatile("" : "+v"(wreg[vg][s]));
+            if constexpr(MP > 1)
+            {
+#pragma unroll
+                for(int p = 1; p < MP; p++)
+                    asm volatile("" : "+v"(wmore[p - 1][vg][s]));
+            }
+        }
 
     const int G = gridDim.x;
     const int t0 = int(xcd_contiguous(blockIdx.x, gridDim.x));
@@ -399,15 +418,12 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
         st1 = 0;
         if constexpr(NCH == 1)
         {
-            // every view pass of the tile from the same LDS buffer.  The next pass's weight fragments (pass 0's for the next tile
-            // after the last pass) are loaded ahead with ordinary loads: the compiler waits for them where wreg is overwritten, by
-            // which time they have long arrived; they are OLDER than that wait's stores, so the hand-counted waits above stay
-            // valid as long as they count only operations that were certainly issued (the stores and the DMA, not these loads).
-            for(int pass = 0; pass < view_passes; pass++)
-            {
-                half8 wnext[VG][2];
-                if(view_passes > 1)
-                    load_weights(pass + 1 == view_passes ? 0 : pass + 1, wnext);
+            // every view pass of the tile from the same LDS buffer, its weight fragments from registers (no loads in this loop: see
+            // the kernel's header)
+            p3_for_each_chunk<MP>([&](auto pass_tag) {
+                constexpr int pass = decltype(pass_tag)::value;
+                if(pass >= view_passes) // uniform
+                    return;
                 const int vw = vw0 + 64 * pass;
                 const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw, 16 * VG)); // ≤ 0: nothing to do for this wave
                 if(nvalid > 0)
@@ -416,25 +432,24 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
 #pragma unroll
                     for(int vg = 0; vg < VG; vg++)
                     {
-                        wk[vg][0] = wreg[vg][0];
-                        wk[vg][1] = wreg[vg][1];
+                        wk[vg][0] = pass == 0 ? wreg[vg][0] : wmore[pass > 0 ? pass - 1 : 0][vg][0];
+                        wk[vg][1] = pass == 0 ? wreg[vg][1] : wmore[pass > 0 ? pass - 1 : 0][vg][1];
                     }
                     compute(wk, buf, kc, std::true_type{});
+                    // Single-pass launches: all of this wave's fetches (the two units in flight) land before its stores go out.
+                    // Measured, not designed — round 2's kernel held such a wait by accident (the compiler's, for pass-weight loads
+                    // that a one-pass launch never issues); without it config 2 runs 2–3 % and one rank of config 4 15 % slower, placed
+                    // in front of the k-loop 1 % and 4 % slower (profiles/r03_p3_drain_ab*.txt).  The two workgroups of a CU fall into
+                    // step: one streams its tiles in while the other computes and writes.  Launches of several passes or several
+                    // chunks are slower with it.
+                    if constexpr(MP == 1)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                     for(int vg = 0; vg < VG; vg++)
                         if(nvalid > 16 * vg) // wave-uniform
                             st1 += epilogue(acc[vg], ct, vw + 16 * vg, min(nvalid - 16 * vg, 16));
                 }
-                if(view_passes > 1)
-                {
-#pragma unroll
-                    for(int vg = 0; vg < VG; vg++)
-                    {
-                        wreg[vg][0] = wnext[vg][0];
-                        wreg[vg][1] = wnext[vg][1];
-                    }
-                }
-            }
+            });
         }
         else
         {

@@ -400,11 +400,11 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
         const char *e = std::getenv("LFI_P3_ABLATE");
         return e ? std::atoi(e) : 0;
     }();
-    if(ablate >= 1 && ablate <= 3 && (nch == 1 || (nch == 4 && a_in.v1 - a_in.v0 <= 64)))
+    if(ablate >= 1 && ablate <= 3 && ((nch == 1 && a_in.v1 - a_in.v0 <= 256) || (nch == 4 && a_in.v1 - a_in.v0 <= 64)))
     {
         note_kernel(c, "blend_p3<ABLATION>");
         const int abl_passes = nch == 1 ? (a_in.v1 - a_in.v0 + 63) / 64 : 1;
-#define LFI_P3_ABL(N, A) hipLaunchKernelGGL((lfi::blend_p3<true, N, A, (N == 1 ? 1 : 2)>), grid, dim3(N == 1 ? 256 : 128), 0, stream_of(c), a_in, tiles_x, n_tiles, abl_passes, 0)
+#define LFI_P3_ABL(N, A) hipLaunchKernelGGL((lfi::blend_p3<true, N, A, (N == 1 ? 1 : 2), (N == 1 ? 4 : 1)>), grid, dim3(N == 1 ? 256 : 128), 0, stream_of(c), a_in, tiles_x, n_tiles, abl_passes, 0)
         if(nch == 1)
         {
             if(ablate == 1) LFI_P3_ABL(1, 1); else if(ablate == 2) LFI_P3_ABL(1, 2); else LFI_P3_ABL(1, 3);
@@ -428,12 +428,23 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
     const dim3 block2(128);
     if(nch == 1)
     {
-        // one chunk of images: every 64-view pass of a tile reads the same LDS-resident pixels (inputs fetched once per launch)
-        const int passes = (a_in.v1 - a_in.v0 + 63) / 64;
-        if(vg_env == 2)
-            hipLaunchKernelGGL((lfi::blend_p3<true, 1, 0, 2>), grid, block2, 0, stream_of(c), a_in, tiles_x, n_tiles, passes, reverse);
-        else
-            hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a_in, tiles_x, n_tiles, passes, reverse);
+        // one chunk of images: every 64-view pass of a tile reads the same LDS-resident pixels — the inputs are fetched once per
+        // 256 views (four passes: the weight fragments a wave keeps in registers)
+        int launch_no = 0;
+        for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 256, launch_no++)
+        {
+            KernelArgs a = a_in;
+            a.v0 = v0;
+            a.v1 = std::min(v0 + 256, a_in.v1);
+            const int passes = (a.v1 - a.v0 + 63) / 64;
+            const int dir = reverse ^ (launch_no & 1);
+            if(vg_env == 2 && passes == 1)
+                hipLaunchKernelGGL((lfi::blend_p3<true, 1, 0, 2>), grid, block2, 0, stream_of(c), a, tiles_x, n_tiles, 1, dir);
+            else if(passes == 1)
+                hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, dir);
+            else
+                hipLaunchKernelGGL((lfi::blend_p3<true, 1, 0, 1, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, dir);
+        }
         return;
     }
     // several chunks: one launch per 64 views

@@ -176,9 +176,10 @@ def test_planar_layout_row_bands(world, cols, W, gpu, oracle_c):
     assert (got == want).all()
 
 
-@pytest.mark.parametrize("V,W,H", [(129, 200, 9), (200, 131, 7), (256, 384, 5)])
+@pytest.mark.parametrize("V,W,H", [(129, 200, 9), (200, 131, 7), (256, 384, 5), (333, 140, 4)])
 def test_planar_layout_three_and_more_view_passes(V, W, H, gpu, oracle_c):
-    """256 views from 64 images (BASELINE config 4 on one GPU): three or more 64-view passes per LDS-resident tile in blend_p3.  Within
+    """256 views from 64 images (BASELINE config 4 on one GPU): three or more 64-view passes per LDS-resident tile in blend_p3 (more than
+    four: a second launch).  Within
     one LSB of the oracle's M16, identical to the RGBA layout's kernel, both sweep directions, a view range that starts inside a pass,
     and a row band."""
     cols = rows = 8

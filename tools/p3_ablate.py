@@ -6,6 +6,8 @@ sys.path.insert(0, ".")
 CFG = {2: (8, 8, 1920, 1080, 64, "0,0,1,1", 0.23, 1.783, 3.0), 3: (15, 15, 1920, 1080, 45, "0,0.5,1,0.5", 0.06, 2.276, 3.0),
        4: (8, 8, 3840, 2160, 32, "0,0,1,1", 0.23, 1.783, 3.0), "4w": (8, 8, 3840, 2160, 256, "0,0,1,1", 0.23, 1.783, 3.0), 5: (15, 15, 3840, 2160, 64, "0.071,0.071,0.93,0.93", 0.22, 1.783, 7.0)}
 if len(sys.argv) > 1:
+    sys.path.insert(0, "tools")
+    import _ablib  # noqa: F401  (LFI_AB_LIB: the measurement build, hipcc -DLFI_MEASUREMENT_BUILD)
     import lfinterpolator_amd as L
     for cfg in (2, 3, 4, "4w", 5):
         cols, rows, W, H, V, traj, focus, aspect, effect = CFG[cfg]
