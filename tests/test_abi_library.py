@@ -112,7 +112,7 @@ def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_pat
     assert sum("blend_stdxI" in k for k in pipelined) == 3    # fixed focus: two, three and four chunks of images
     assert sum("blend_stdxaI" in k for k in pipelined) == 4   # all-focus: one to four chunks
     assert len(pipelined) >= 10, sorted(kernels)
-    p3_name = re.compile(r"blend_p3ILb1ELi(\d)ELi(\d)ELi(\d)EEEv")  # <true, chunks, ablation, view groups per wave>
+    p3_name = re.compile(r"blend_p3ILb1ELi(\d)ELi(\d)ELi(\d)ELi(\d)EEEv")  # <true, chunks, ablation, view groups per wave, view passes>
     n_two_groups = 0
     for k in pipelined:
         assert kernels[k][".private_segment_fixed_size"] == 0 and kernels[k][".vgpr_spill_count"] == 0, (k, kernels[k])
@@ -136,9 +136,14 @@ def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_pat
         elif cur:
             body[cur].append(line)
     shipped = [k for k in body if p3_name.search(k) and p3_name.search(k).group(2) == "0"]
-    assert len(shipped) >= 7, sorted(body)
+    assert len(shipped) >= 8, sorted(body)
+    assert sum(p3_name.search(k).group(4) == "4" for k in shipped) == 1     # up to four view passes: one chunk of images, 16 views per wave
     for k in shipped:
         text = "\n".join(body[k])
+        if p3_name.search(k).group(4) == "4":
+            # the pass loop holds no load the compiler would have to wait for behind predicated stores (round 2: s_waitcnt vmcnt(0) per pass)
+            loop = text[text.index("s_barrier", text.index("s_barrier") + 1):]
+            assert "global_load_dwordx4" not in loop, k
         n_st, n_dma = len(re.findall(r"global_store_dwordx4", text)), len(re.findall(r"global_load_lds_dwordx4", text))
         assert n_st >= 6 and n_st % 6 == 0 and len(re.findall(r"global_store_", text)) == n_st, (k, n_st)
         assert n_dma >= 18 and n_dma % 6 == 0, (k, n_dma)
