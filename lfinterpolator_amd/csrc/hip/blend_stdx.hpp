@@ -11,11 +11,11 @@
 //                    MC(0)             the last k-loop, on chunk 0; epilogue: band test on all sums, RGBA stores of the rounded bytes,
 //                                      the sums inside the band queued per wave (≤ 128; more take a slow path); the chain's first 64
 //                                      images for the queued sums — chunk 0 is the one buffer still resident
-//                    C(1) … C(NCH−1)   the same chunks fetched AGAIN through the same LDS-DMA ring (they left this workgroup's L2 /
-//                                      the Infinity Cache microseconds ago), chain continued in ascending image order; after the last
-//                                      one the chain's bytes are patched over the rounded ones (byte stores by the wave that wrote the
-//                                      dwords: same-wave stores to one address retire in order).  C(1) fetches nothing: chunk 1 is
-//                                      still in the buffer M(1) left (sx_buffer below).
+//                    C(1) … C(NCH−1)   the chain continued in ascending image order over the same chunks: chunks 1 and 2 are still in the
+//                                      buffers M(1) and M(2) left (sx_buffer below); chunk 3 is fetched AGAIN through the same LDS-DMA
+//                                      ring (it left this workgroup's L2 / the Infinity Cache microseconds ago).  After the last unit
+//                                      the chain's bytes are patched over the rounded ones (byte stores by the wave that wrote the
+//                                      dwords: same-wave stores to one address retire in order).
 //
 // so HBM sees the inputs once; the second fetch is cache traffic.  Pipeline (persistent workgroups, ring of three buffers two units
 // ahead, one barrier and one hand-counted vmcnt wait per unit), operand maps, DMA addressing: blend_p3.hpp, four waves of 16 views.
@@ -44,9 +44,11 @@ constexpr int SX_QCAP = 128; // queued (pixel, view, channel) sums per wave and 
 #endif
 
 // The ring buffer of unit `sl` (0 … 2·NCH − 2: M(NCH−1) … M(1), MC(0), C(1) … C(NCH−1)) of a workgroup's j-th tile.  Fetches run two units
-// ahead, each into the buffer of the unit that finished last — except that C(1) fetches NOTHING: chunk 1 of the tile is what M(1), two units
-// earlier, left in its buffer, which is therefore kept until C(1) is done (the all-focus kernel's observation, blend_stdxa.hpp, carried
-// over to a ring of three).  Written out, the assignment repeats with period two tiles, the second tile mirrored (2 − buffer):
+// ahead, each into the buffer of the unit that finished last — except that C(1) and C(2) fetch NOTHING: chunks 1 and 2 of the tile are what
+// M(1) and M(2) left in their buffers, which the assignment below leaves untouched until C(1) and C(2) are done (the all-focus kernel's
+// observation, blend_stdxa.hpp, carried over to a ring of three).  With four chunks only chunk 3 — overwritten by MC(0)'s chunk 0 — comes
+// back a second time; with two or three chunks nothing does.  Written out, the assignment repeats with period two tiles, the second tile
+// mirrored (2 − buffer):
 template <int NCH>
 __host__ __device__ constexpr int sx_buffer(const int j, const int sl)
 {
@@ -261,7 +263,9 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
     const int T = (n_tiles - 1 - t0) / G + 1;
     auto slot_valid = [&](const int j, const int sl) { return j < T && sl < NU; };
     auto slot_chunk = [](const int sl) { return sl < NCH ? NCH - 1 - sl : sl - NCH + 1; };
-    auto slot_fetches = [](const int sl) { return sl != NCH; }; // C(1) reads the buffer M(1) left
+    // C(1) and C(2) read the buffers M(1) and M(2) left: nothing was fetched into them in between (sx_buffer: only C(3)'s chunk was
+    // overwritten, by MC(0)'s)
+    auto slot_fetches = [](const int sl) { return sl < NCH || sl > NCH + 1; };
     int ij = 0, isl = 0; // issue cursor: the next unit to fetch; past the end when ij ≥ T
     auto advance_issue = [&] {
         do
