@@ -420,11 +420,13 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
     const int reverse = next_sweep_direction(c);
     // Views per wave: 16 (four waves per workgroup, two per SIMD) when the launch is paced by its memory pipeline — one chunk of
     // images — and 32 (two waves per workgroup, one per SIMD, the pixel operand built once for two MFMAs) when several chunks make the
-    // k-loop the pacer (15×15 grids: −13 % at 4K, profiles/r02_p3_vg.txt).  LFI_P3_VG = 1 / 2 forces either (measurements only).
+    // k-loop the pacer (15×15 grids: −13 % at 4K, profiles/r02_p3_vg.txt).  Measurement builds: LFI_P3_VG = 1 / 2 forces either (tools/p3_vg.py).
+#ifdef LFI_MEASUREMENT_BUILD
     static const int vg_env = [] {
         const char *e = std::getenv("LFI_P3_VG");
         return e ? std::atoi(e) : 0;
     }();
+#endif
     const dim3 block2(128);
     if(nch == 1)
     {
@@ -438,9 +440,14 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
             a.v1 = std::min(v0 + 256, a_in.v1);
             const int passes = (a.v1 - a.v0 + 63) / 64;
             const int dir = reverse ^ (launch_no & 1);
+#ifdef LFI_MEASUREMENT_BUILD
             if(vg_env == 2 && passes == 1)
+            {
                 hipLaunchKernelGGL((lfi::blend_p3<true, 1, 0, 2>), grid, block2, 0, stream_of(c), a, tiles_x, n_tiles, 1, dir);
-            else if(passes == 1)
+                continue;
+            }
+#endif
+            if(passes == 1)
                 hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, dir);
             else
                 hipLaunchKernelGGL((lfi::blend_p3<true, 1, 0, 1, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, dir);
@@ -454,10 +461,16 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
         a.v0 = v0;
         a.v1 = std::min(v0 + 64, a_in.v1);
 #define LFI_P3_LAUNCH(N)                                                                                                                        \
-    if(vg_env == 1)                                                                                                                             \
-        hipLaunchKernelGGL((lfi::blend_p3<true, N, 0, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse);                        \
-    else                                                                                                                                        \
-        hipLaunchKernelGGL((lfi::blend_p3<true, N, 0, 2>), grid, block2, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse)
+    hipLaunchKernelGGL((lfi::blend_p3<true, N, 0, 2>), grid, block2, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse)
+#ifdef LFI_MEASUREMENT_BUILD
+        if(vg_env == 1)
+        {
+            if(nch == 2) hipLaunchKernelGGL((lfi::blend_p3<true, 2, 0, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse);
+            else if(nch == 3) hipLaunchKernelGGL((lfi::blend_p3<true, 3, 0, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse);
+            else hipLaunchKernelGGL((lfi::blend_p3<true, 4, 0, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse);
+            continue;
+        }
+#endif
         switch(nch)
         {
             case 2: LFI_P3_LAUNCH(2); break;

@@ -136,7 +136,7 @@ def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_pat
         elif cur:
             body[cur].append(line)
     shipped = [k for k in body if p3_name.search(k) and p3_name.search(k).group(2) == "0"]
-    assert len(shipped) >= 8, sorted(body)
+    assert len(shipped) >= 5, sorted(body)   # one chunk: one pass / up to four; two to four chunks: two waves of 32 views
     assert sum(p3_name.search(k).group(4) == "4" for k in shipped) == 1     # up to four view passes: one chunk of images, 16 views per wave
     for k in shipped:
         text = "\n".join(body[k])

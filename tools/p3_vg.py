@@ -1,4 +1,4 @@
-"""blend_p3 with four waves x 16 views per workgroup (LFI_P3_VG=1) against two waves x 32 views (LFI_P3_VG=2) at configs 2, 3, 4-rank,
+"""(measurement build of the library: hipcc -DLFI_MEASUREMENT_BUILD, LFI_AB_LIB)  blend_p3 with four waves x 16 views per workgroup (LFI_P3_VG=1) against two waves x 32 views (LFI_P3_VG=2) at configs 2, 3, 4-rank,
 4-whole (256 views: four view passes per tile) and 5 — one process per setting, alternating, same box.  (Unset, the library picks 16 views
 per wave for one chunk of images and 32 for several.)   usage: python tools/p3_vg.py"""
 import os, subprocess, sys
