@@ -227,6 +227,13 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
                                     "kernel": "focus_factored passes + focus_filter", "ms": ms_map,
                                     "algorithmic_bytes": map_in + map_io, "frac": (map_in + map_io) / ms_map / 1e6 / HBM_PEAK_GBS,
                                     "note": "bound by VALU issue / L2 (DESIGN.md 4.3), not HBM: the fraction is reported for completeness"}
+        # the same call when the inputs changed since the last one: the padded copies of the sampled images are rebuilt (otherwise kept
+        # between calls — a focus sweep over one light field, which is what BASELINE config 5 is, pads once)
+        ms_map_cold = timed(ctx, lambda: (ctx.grid_modified(), ctx.focus_map()), max(2, iters // 4), warm=1)
+        out["config5_focus_map_inputs_changed"] = {"workload": out["config5_focus_map"]["workload"], "kernel": "focus_pad + focus_factored passes + focus_filter",
+                                                   "ms": ms_map_cold, "algorithmic_bytes": map_in + map_io,
+                                                   "frac": (map_in + map_io) / ms_map_cold / 1e6 / HBM_PEAK_GBS,
+                                                   "note": "lfi_grid_modified before every call: every estimate pads its sampled images again (round 2's behaviour)"}
         for method in ("TEN_WM", "STD"):
             ms_r = timed(ctx, lambda: ctx.render(method, all_focus=True), max(2, iters // 4), warm=1)
             k = ctx.last_kernel_name()
@@ -267,6 +274,7 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
             out[key + "_cold_one_shot"] = entry(cfg, sorted(res)[1], cfg["views"], k,
                                                 f"a fresh context's first render, caches flushed, one sweep direction: includes whatever the "
                                                 f"library derives from the inputs first ({mem.derived_bytes / 1e6:.0f} MB derived copy); median of 3")
+            out[key + "_cold_one_shot"]["reps_ms"] = [round(r, 3) for r in res]   # a first hipMalloc of gigabytes can take 100+ ms on a box
         del flush
 
     guarded(cold_one_shot)

@@ -194,7 +194,11 @@ int lfi_views_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes);
 
 /* ---- kernels ------------------------------------------------------------------------------------------------ */
 
-/* FocusMap::estimate + FocusMap::filter launches (src/interpolator.cu:261-266): fills maps 0 and 1. */
+/* FocusMap::estimate + FocusMap::filter launches (src/interpolator.cu:261-266): fills maps 0 and 1.
+ * The estimate reads edge-padded copies of the <= 32 sampled images; they depend on the inputs only (and on a bound of the shifts),
+ * so they are kept between calls and rebuilt when the images change (any upload / fill through this library, lfi_grid_modified for
+ * writes through the raw pointer), when other images are sampled, or when the shifts outgrow the padding: a focus sweep over one
+ * light field (the reference's focusMapCompare.sh loop) pads once. */
 int lfi_focus_map(lfi_ctx *ctx);
 /* One launch of Tensors::process / Standard::process (src/interpolator.cu:274-288) for views [v0, v1).
  * all_focus != 0 selects the <true> instantiations (per-pixel focus from the focus map). */

@@ -98,6 +98,12 @@ struct lfi_ctx
     bool grid_tracked = true; // every write to the planes goes through this library (or is announced by lfi_grid_modified)
     void *focus_ws = nullptr; // workspace of the factored focus-map estimate (plan, E, K), allocated on first use
     size_t focus_ws_bytes = 0;
+    // the estimate's padded copies of the sampled images (focus_pad, the tail of focus_ws) depend on the inputs and on a BOUND of the
+    // candidates' shifts only: kept between lfi_focus_map calls (a focus sweep over one light field — BASELINE config 5 — pads once)
+    // while pad_version == grid_version, the same images are sampled with the same block radius, and pad_shift still covers the request
+    uint64_t pad_version = 0;
+    int pad_shift[2] = {0, 0}, pad_radius[2] = {0, 0};
+    std::vector<int32_t> pad_ids, h_focus_ids;
     int ten_variant = 0, std_variant = 0, focus_variant = 0;
     mutable const char *last_kernel = ""; // the blend kernel the last render launched (lfi_last_kernel_name)
     mutable unsigned sweep_launches = 0;  // blend_p3 / blend_planar alternate their sweep direction from launch to launch
@@ -407,6 +413,7 @@ void free_grid(lfi_ctx *c)
         (void)hipFree(c->focus_ws);
     c->focus_ws = nullptr;
     c->focus_ws_bytes = 0;
+    c->pad_version = 0;
     if(c->planar)
         (void)hipFree(c->planar);
     c->planar = nullptr;

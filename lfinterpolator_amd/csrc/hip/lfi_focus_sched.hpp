@@ -29,7 +29,14 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     }
     if(!(fmax * ox < 1e6 && fmax * oy < 1e6))
         return LFI_OK;
-    const int Sx = (int)std::ceil(fmax * ox) + 1, Sy = (int)std::ceil(fmax * oy) + 1; // ≥ |floor(δ)| and ≥ |floor(δ)+1|
+    int Sx = (int)std::ceil(fmax * ox) + 1, Sy = (int)std::ceil(fmax * oy) + 1; // ≥ |floor(δ)| and ≥ |floor(δ)+1|
+    // The padded planes of an earlier call serve this one if the inputs have not changed since and their padding covers these shifts
+    // (any larger padding gives the same samples): then the geometry is theirs.  New planes are padded to the next multiple of 8, so
+    // that the neighbouring steps of a focus sweep find them large enough.
+    const bool pad_kept = ctx->grid_tracked && ctx->focus_ws && ctx->pad_version == ctx->grid_version && ctx->pad_ids == ctx->h_focus_ids &&
+                          ctx->pad_radius[0] == rx && ctx->pad_radius[1] == ry && ctx->pad_shift[0] >= Sx && ctx->pad_shift[1] >= Sy;
+    Sx = pad_kept ? ctx->pad_shift[0] : (Sx + 7) / 8 * 8;
+    Sy = pad_kept ? ctx->pad_shift[1] : (Sy + 7) / 8 * 8;
     w.Px = Sx + rx;
     w.Py = Sy + ry;
     w.Wp = (w.Px + std::max(W + Sx + rx, w.We_p - rx + Sx) + 3) / 4 * 4;
@@ -66,6 +73,7 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
             (void)hipFree(ctx->focus_ws);
         ctx->focus_ws = nullptr;
         ctx->focus_ws_bytes = 0;
+        ctx->pad_version = 0;
         LFI_HIP(ctx, hipMalloc(&ctx->focus_ws, at));
         ctx->focus_ws_bytes = at;
     }
@@ -107,7 +115,16 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     // host launch order = the critical path first: the main stream's kernels are enqueued before the side stream's
     hipLaunchKernelGGL(lfi::focus_plan_shifts, dim3(1), dim3(1024), 0, st, a, w);
     LFI_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
-    hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, ctx->n_focus_ids), dim3(64), 0, st, a, w);
+    if(!(pad_kept && ctx->pad_version == ctx->grid_version)) // (a reallocated workspace cleared pad_version)
+    {
+        hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, ctx->n_focus_ids), dim3(64), 0, st, a, w);
+        ctx->pad_version = ctx->grid_tracked ? ctx->grid_version : 0;
+        ctx->pad_shift[0] = Sx;
+        ctx->pad_shift[1] = Sy;
+        ctx->pad_radius[0] = rx;
+        ctx->pad_radius[1] = ry;
+        ctx->pad_ids = ctx->h_focus_ids;
+    }
     LFI_HIP(ctx, hipEventRecord(ctx->ev_pad, st));
     const uint32_t tiles_x = uint32_t(w.We_p / 256), tiles_y = uint32_t(w.He_p / 4);
     {

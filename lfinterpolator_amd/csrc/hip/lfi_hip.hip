@@ -520,6 +520,7 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     ctx->h_focus_offsets.clear();
     for(int k = 0; k < p->n_focus_ids; k++)
         ctx->h_focus_offsets.push_back(p->offsets[p->focus_map_ids[k]]);
+    ctx->h_focus_ids.assign(p->focus_map_ids, p->focus_map_ids + p->n_focus_ids);
     ctx->focus = p->focus;
     ctx->range = p->range;
     for(int d = 0; d < 2; d++)

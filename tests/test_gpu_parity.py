@@ -443,6 +443,49 @@ def test_focus_map_realistic_geometry(radius, gpu, oracle_c):
 
 
 
+def test_focus_map_padded_planes_are_kept_between_calls(gpu, oracle_c):
+    """lfi_focus_map keeps the padded copies of the sampled images while the inputs are unchanged (a focus sweep over one light field pads
+    once).  Every call must still give the oracle's bytes: the same parameters again (planes reused), a smaller and a larger focus
+    (reused / rebuilt with more padding), another block radius (rebuilt), one sampled image replaced (rebuilt), a write through the raw
+    grid pointer announced by lfi_grid_modified (rebuilt)."""
+    cols, rows, W, H = 8, 8, 333, 90
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, 77)
+    lf = (lf // 16 * 16).astype(np.uint8)
+    lf[..., 3] = 255
+
+    def params(focus, rng, radius=None):
+        hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", focus, rng, 7.0, 1.783, 4)
+        if radius is not None:
+            hp.block_radius = np.array(radius, np.int32)
+        return hp
+
+    def check(ctx, hp, lf_now, what):
+        ctx.set_params(hp)
+        ctx.focus_map()
+        ctx.sync()
+        want0 = oracle_c.focus_estimate(lf_now, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, threads=8)
+        got = ctx.download_map(0)
+        assert (got == want0).all(), (what, int((got != want0).sum()))
+        assert (ctx.download_map(1) == oracle_c.focus_filter(want0, hp.block_radius)).all(), what
+
+    hp = params(0.22, 0.17)
+    ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    ctx.set_variant("FOCUS", "factored")
+    check(ctx, hp, lf, "first call")
+    check(ctx, hp, lf, "same parameters: planes reused")
+    check(ctx, params(0.10, 0.05), lf, "smaller shifts: planes reused")
+    check(ctx, params(0.22, 0.17), lf, "back")
+    check(ctx, params(0.9, 0.6), lf, "larger shifts: rebuilt")
+    check(ctx, params(0.22, 0.17, (3, 1)), lf, "another block radius")
+    lf2 = lf.copy()
+    g = int(hp.focus_map_ids[1])
+    lf2[g] = lf2[g][::-1, ::-1]              # one of the sampled images, replaced through the library
+    ctx.upload_image(g, lf2[g])
+    check(ctx, params(0.22, 0.17, (3, 1)), lf2, "a sampled image replaced")
+    check(ctx, params(0.22, 0.17, (3, 1)), lf2, "and reused again")
+    ctx.close()
+
+
 def _random_cases(n, seed):
     rng = np.random.default_rng(seed)
     cases = []
