@@ -23,7 +23,7 @@ def fuzz_blend(L, oc, n_cases: int, seed: int, log=None) -> list:
             cols, rows = 3, 4
         W = int(rng.choice([1, 4, 31, 33, 64, 100, 127, 128, 129, 191, 256, 300, 513, 700]))
         H = int(rng.integers(1, 10))
-        V = int(rng.choice([1, 3, 31, 32, 33, 64, 65, 100, 129]))
+        V = int(rng.choice([1, 3, 31, 32, 33, 64, 65, 100, 129, 200, 300]))
         focus = float(rng.choice([0.0, 0.03, 0.23, 0.5, 1.1, -0.4]))
         traj = str(rng.choice(["0,0,1,1", "0.071,0.071,0.93,0.93", "1,0,0,1", "0.5,0.5,0.5,0.5", "0.2,0.9,0.8,0.1"]))
         effect = float(rng.choice([1.0, 3.0, 7.0]))
