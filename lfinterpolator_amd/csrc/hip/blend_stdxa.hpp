@@ -59,7 +59,18 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
     auto unit_chunk = [](const int u) { return u < NCH ? NCH - 1 - u : u - NCH + 1; };
 
     // ---- LDS-DMA of one unit (tile t, chunk) into buffers b: weight fragments + the per-pixel gather (blend_persist's) --------------------
-    auto issue = [&](const int t, const int chunk, const int b) {
+    // the focus values of this lane's two pixels of a tile: fetched one unit before the tile's first gathers, kept for all its chunks
+    // (blend_ten_persist.hpp: map_raw / map_focus)
+    auto map_raw = [&](const int t, uint32_t &m0, uint32_t &m1) {
+        const int ty = t / tiles_x;
+        const int y = clampi(a.out_y0 + ty, 0, H - 1);
+        const int x0 = (t - ty * tiles_x) * TPX;
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(map_plane) + (size_t)y * W;
+        m0 = row[clampi(x0 + lane, 0, W - 1)];
+        m1 = row[clampi(x0 + 64 + lane, 0, W - 1)];
+    };
+    auto map_focus = [&](const uint32_t m) { return __builtin_fmaf(__fdiv_rn(static_cast<float>(m & 0xffu), 255.0f), a.range, a.focus); };
+    auto issue = [&](const int t, const int chunk, const int b, const float f0, const float f1) {
         const int ty = t / tiles_x;
         const int y = a.out_y0 + ty;
         const int x0 = (t - ty * tiles_x) * TPX;
@@ -71,8 +82,6 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
         for(int o = wave; 8 * o < kc; o += C::NW)
             if(lane < VPP)
                 dma16(a.w16s + (size_t)(a.v0 + lane) * a.k_pad + k0 + 8 * o, w_addr + uint32_t(o) * (VPP * 16));
-        const float f0 = decode_focus(map_plane, W, H, x0 + lane, y, a.focus, a.range);
-        const float f1 = decode_focus(map_plane, W, H, x0 + 64 + lane, y, a.focus, a.range);
         const float xf0 = static_cast<float>(x0 + lane), xf1 = static_cast<float>(x0 + 64 + lane), yf = static_cast<float>(y);
         int gi = wave;
         float ox = 0.0f, oy = 0.0f;
@@ -141,7 +150,14 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
     if(t >= n_tiles)
         return;
     int buf = 0, prev_stores = 0;
-    issue(t, unit_chunk(0), 0);
+    float f0, f1; // the focus values of the tile whose units are being issued
+    {
+        uint32_t m0, m1;
+        map_raw(t, m0, m1);
+        f0 = map_focus(m0);
+        f1 = map_focus(m1);
+    }
+    issue(t, unit_chunk(0), 0, f0, f1);
     const int nviews = min(a.v1 - a.v0, VPP);
     uint32_t entry0 = 0u, entry1 = 0u; // bit 15: valid
     float s0 = 0.0f, s1 = 0.0f;
@@ -152,6 +168,11 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
         constexpr int u = decltype(u_tag)::value;
         constexpr int cc = u < NCH ? NCH - 1 - u : u - NCH + 1;
         constexpr bool is_m = u < NCH, is_mc = u == NCH - 1, is_last = u == NU - 1;
+        // the last unit of a tile issues the next tile's first gathers: that tile's map values now, beside the pieces in flight (younger
+        // than the stores counted below: the wait only becomes stricter)
+        uint32_t m0n = 0u, m1n = 0u;
+        if(u == NU - 1 && t + G < n_tiles)
+            map_raw(t + G, m0n, m1n);
         // this wave's pieces of the current unit have landed; the previous epilogue's stores (the youngest operations) may be in flight
         if(prev_stores >= 32)
             asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -171,8 +192,13 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
         // The unit after MC(0) is C(1), and chunk 1 of this very tile is what the unit before MC(0), M(1), left in the other pair of buffers
         // (pixels and weights): nothing is fetched for it.  (blend_stdx's ring of three has overwritten that buffer by then.)
         constexpr bool next_is_resident = is_mc && NCH >= 2;
+        if(last_of_tile && have_next)
+        {
+            f0 = map_focus(m0n);
+            f1 = map_focus(m1n);
+        }
         if(have_next && !next_is_resident)
-            issue(nt, unit_chunk(last_of_tile ? 0 : u + 1), buf ^ 1);
+            issue(nt, unit_chunk(last_of_tile ? 0 : u + 1), buf ^ 1, f0, f1);
         prev_stores = 0;
 
         const int kc = min(KC, a.k_pad - KC * cc);

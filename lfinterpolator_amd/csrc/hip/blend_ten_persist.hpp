@@ -123,7 +123,22 @@ __global__ void __launch_bounds__(256, WGS)
         return so;
     };
 
-    auto issue = [&](int t, int pass, int k0, int pb, int wb, bool with_pixels, const SlotOffsets &so) {
+    // all-focus: the focus values of this lane's two pixels of a tile (pixels x0 + lane and x0 + 64 + lane), raw map dwords first.  They
+    // are fetched ONE UNIT EARLIER than the gathers that need them, and only when the tile changes (the chunks of a tile share them):
+    // round 2 loaded them inside `issue`, right after the barrier — two dependent L2 latencies (the compiler waits with vmcnt(0) after
+    // each) in front of every unit's gathers.
+    const uint8_t *map_plane = ALLFOCUS ? a.maps + (size_t)a.map_index * (size_t)W * H * 4 : nullptr; // maps are whole-image planes
+    auto map_raw = [&](const int t, uint32_t &m0, uint32_t &m1) {
+        const int ty = t / tiles_x;
+        const int y = clampi(a.out_y0 + ty, 0, H - 1);
+        const int x0 = (t - ty * tiles_x) * TPX;
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(map_plane) + (size_t)y * W;
+        m0 = row[clampi(x0 + lane, 0, W - 1)];
+        m1 = row[clampi(x0 + 64 + lane, 0, W - 1)];
+    };
+    // loadFocusFromMap (src/kernels.cu:134-137): decode_focus's arithmetic on a map dword that is already here
+    auto map_focus = [&](const uint32_t m) { return __builtin_fmaf(__fdiv_rn(static_cast<float>(m & 0xffu), 255.0f), a.range, a.focus); };
+    auto issue = [&](int t, int pass, int k0, int pb, int wb, bool with_pixels, const SlotOffsets &so, const float f0, const float f1) {
         const int ty = t / tiles_x;
         const int y = a.out_y0 + ty; // global row
         const int x0 = (t - ty * tiles_x) * TPX;
@@ -194,9 +209,6 @@ __global__ void __launch_bounds__(256, WGS)
             // index; the plane's base (minus the rows above the held window) stays in an SGPR pair, the images' float offsets are
             // read one iteration ahead through the scalar cache.  (The first version spent ≈400 issue cycles per image on 64-bit
             // vector multiplies and an exposed scalar load: all-focus renders ran 3× slower than fixed-focus ones.)
-            const uint8_t *map_plane = a.maps + (size_t)a.map_index * (size_t)W * H * 4; // maps are whole-image planes
-            const float f0 = decode_focus(map_plane, W, H, x0 + lane, y, a.focus, a.range);
-            const float f1 = decode_focus(map_plane, W, H, x0 + 64 + lane, y, a.focus, a.range);
             const float xf0 = static_cast<float>(x0 + lane), xf1 = static_cast<float>(x0 + 64 + lane), yf = static_cast<float>(y);
             int gi = wave;
             float ox = 0.0f, oy = 0.0f;
@@ -235,7 +247,15 @@ __global__ void __launch_bounds__(256, WGS)
     int pass = 0, k0 = 0, pbuf = 0, wbuf = 0;
     int prev_stores = 0; // store instructions this wave issued in the previous epilogue (they are the youngest VMEM ops)
     SlotOffsets slot_offsets = load_offsets(0);
-    issue(t, 0, 0, 0, 0, true, slot_offsets);
+    float f0 = 0.0f, f1 = 0.0f; // the focus values of the tile whose units are being issued
+    if constexpr(ALLFOCUS)
+    {
+        uint32_t m0, m1;
+        map_raw(t, m0, m1);
+        f0 = map_focus(m0);
+        f1 = map_focus(m1);
+    }
+    issue(t, 0, 0, 0, 0, true, slot_offsets, f0, f1);
 
     f32x16 acc[MT][3];
 #pragma unroll
@@ -264,6 +284,13 @@ __global__ void __launch_bounds__(256, WGS)
         const bool next_needs_pixels = !single_chunk || nt != t;
         const int npbuf = next_needs_pixels ? (pbuf ^ 1) : pbuf;
 
+        // the next unit starts a new tile: its map values now, so that they travel beside the pieces in flight.  (Younger than the stores
+        // counted below: the wait only becomes stricter.)
+        uint32_t m0n = 0u, m1n = 0u;
+        const bool new_tile = ALLFOCUS && have_next && nt != t;
+        if(new_tile)
+            map_raw(nt, m0n, m1n);
+
         // (A) this wave's pieces of the current unit have landed; the previous epilogue's stores may still be in flight.
         // vmcnt retires in order and the stores are the youngest operations, so waiting for "at most prev_stores outstanding"
         // covers every DMA piece; the immediate is the largest threshold not above the exact count.
@@ -283,7 +310,12 @@ __global__ void __launch_bounds__(256, WGS)
         {
             if(!single_chunk && !ALLFOCUS)
                 slot_offsets = load_offsets(nk0);
-            issue(nt, npass, nk0, npbuf, wbuf ^ 1, next_needs_pixels, slot_offsets);
+            if(new_tile)
+            {
+                f0 = map_focus(m0n);
+                f1 = map_focus(m1n);
+            }
+            issue(nt, npass, nk0, npbuf, wbuf ^ 1, next_needs_pixels, slot_offsets, f0, f1);
         }
 
         // ---- compute the current unit ------------------------------------------------------------------------------------------------
