@@ -140,6 +140,11 @@ def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_pat
     assert sum(p3_name.search(k).group(4) == "4" for k in shipped) == 1     # up to four view passes: one chunk of images, 16 views per wave
     for k in shipped:
         text = "\n".join(body[k])
+        if p3_name.search(k).group(1) == "1" and p3_name.search(k).group(3) == "1" and p3_name.search(k).group(4) == "1":
+            # the one-pass kernel lets all its fetches land between its last MFMA and its first store (profiles/r03_notes.md §11: −2 % at
+            # config 2, −7 … −15 % per rank of config 4; round 2 had this wait by accident, a clean-up lost it once)
+            tail = text[text.rindex("v_mfma_f32_16x16x32_f16"):]
+            assert "s_waitcnt vmcnt(0)" in tail[:tail.index("global_store_dwordx4")], k
         if p3_name.search(k).group(4) == "4":
             # the pass loop holds no load the compiler would have to wait for behind predicated stores (round 2: s_waitcnt vmcnt(0) per pass)
             loop = text[text.index("s_barrier", text.index("s_barrier") + 1):]
