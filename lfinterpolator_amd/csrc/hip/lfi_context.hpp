@@ -116,7 +116,7 @@ namespace {
 // The context's own views in the planar layout live in UNCACHED device memory: they are write-only for the renders (full 128-byte
 // lines, non-temporal stores), and planes that bypass the caches leave more of the Infinity Cache to the inputs the next launch
 // re-reads (tools/views_mtype.py, config 2: 150 µs against 156 µs per launch).  RGBA views stay in ordinary memory (the STD band
-// epilogue patches single bytes behind its dword stores).  LFI_VIEWS_MEMORY=default|uncached|finegrained overrides (experiments).
+// epilogue patches single bytes behind its dword stores).  Measurement builds: LFI_VIEWS_MEMORY=default|uncached|finegrained overrides.
 //
 // Uncached blocks are NEVER handed back to the HIP runtime while the process lives (round 3).  Freed with hipFree, their address range
 // is recycled for later ordinary allocations — and contexts created after a few such cycles rendered garbage from ordinary memory
@@ -169,10 +169,14 @@ bool uncached_release(void *p) // true: p was one of ours (kept for reuse); fals
 
 hipError_t alloc_views(uint8_t **out, size_t bytes, bool planar_layout, int device)
 {
+#ifdef LFI_MEASUREMENT_BUILD
     static const int forced = [] {
         const char *e = std::getenv("LFI_VIEWS_MEMORY");
         return !e ? -1 : (std::strcmp(e, "uncached") == 0 ? 1 : (std::strcmp(e, "finegrained") == 0 ? 2 : 0));
     }();
+#else
+    constexpr int forced = -1;
+#endif
     const int kind = forced >= 0 ? forced : (planar_layout ? 1 : 0);
     if(kind == 1)
         return uncached_alloc(out, bytes, device);

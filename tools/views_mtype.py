@@ -1,4 +1,4 @@
-"""The views of the planar layout in ordinary / uncached device memory (LFI_VIEWS_MEMORY=default|uncached; the library's choice for its
+"""(measurement build of the library: hipcc -DLFI_MEASUREMENT_BUILD, LFI_AB_LIB)  The views of the planar layout in ordinary / uncached device memory (LFI_VIEWS_MEMORY=default|uncached; the library's choice for its
 own planar views is uncached): write-only planes that bypass the caches leave more of the Infinity Cache to the inputs of the next
 launch — measured per BASELINE config, alternating processes on one box.   usage: python tools/views_mtype.py"""
 import os, subprocess, sys
