@@ -860,8 +860,10 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
     const focus_const_u32_ptr chunk_prefix = prefix + 66;
     const focus_const_int_ptr ncols = (focus_const_int_ptr)(uintptr_t)w.ncols;
     auto encode = [](const uint32_t sum) { return focus_key_encode(sum); };
-    // (R)
-    const uint32_t chunks_w = uint32_t((W + 63) / 64);
+    // (R)  a wave's work item = four 64-pixel chunks of one flagged (row, candidate) entry: the entry's row, slot and tap flags are a chain
+    // of dependent loads, paid once per item
+    constexpr uint32_t CG = 4;
+    const uint32_t chunks_w = (uint32_t((W + 63) / 64) + CG - 1) / CG;
     int i = 0;
     for(uint32_t u = wave_id; u < prefix[32] * chunks_w; u += n_waves)
     {
@@ -871,21 +873,28 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
         const uint32_t slot = __builtin_amdgcn_readfirstlane(line_slot(w.rowbase[y], w.bady[y], i));
         if(slot >= uint32_t(w.R_cap))
             continue; // focus_exact (B)
-        const int x = int(u % chunks_w) * 64 + lane;
-        if(x >= W || ((w.badx[x] >> i) & 1u))
-            continue; // flagged on both axes: focus_exact (A)
         // per tap row: the row's own line where the uniform shift fails for it (wave-uniform), the candidate's plane of E otherwise
-        uint32_t sum = 0;
+        const uint16_t *line[3];
 #pragma unroll
         for(int ty = 0; ty < 3; ty++)
         {
             const bool own = (__builtin_amdgcn_readfirstlane(w.tapy[(size_t)ty * H + y]) >> i) & 1u;
-            const uint16_t *line = own ? w.Er + ((size_t)slot * 3 + ty) * w.We_p + x : w.E + ((size_t)i * w.He_p + y + ty * ry) * w.We_p + x;
-#pragma unroll
-            for(int tx = 0; tx < 3; tx++)
-                sum += line[tx * rx];
+            line[ty] = own ? w.Er + ((size_t)slot * 3 + ty) * w.We_p : w.E + ((size_t)i * w.He_p + y + ty * ry) * w.We_p;
         }
-        w.K[((size_t)i * H + y) * W + x] = static_cast<uint16_t>(encode(sum));
+#pragma unroll
+        for(uint32_t c = 0; c < CG; c++)
+        {
+            const int x = int((u % chunks_w) * CG + c) * 64 + lane;
+            if(x >= W || ((w.badx[x] >> i) & 1u))
+                continue; // flagged on both axes: focus_exact (A)
+            uint32_t sum = 0;
+#pragma unroll
+            for(int ty = 0; ty < 3; ty++)
+#pragma unroll
+                for(int tx = 0; tx < 3; tx++)
+                    sum += line[ty][x + tx * rx];
+            w.K[((size_t)i * H + y) * W + x] = static_cast<uint16_t>(encode(sum));
+        }
     }
     // (C)
     constexpr int ROWS = 8;
