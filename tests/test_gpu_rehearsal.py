@@ -57,3 +57,17 @@ def test_two_rank_rehearsal_row_bands(gpu):
     assert "rows sharded over 2 GPU(s)" in cfg["parallelism"] and "no collective" in cfg["parallelism"]
     assert cfg["row_bands"] == [[0, 540], [540, 1080]]
     assert line["value"] > 0
+
+
+def test_two_rank_rehearsal_default_run(gpu):
+    """The contract's own command (`bench.py --gpus 2 --steps K --warmup W`, what the driver's SCALE run launches): BASELINE config 2 per
+    rank, weak-scaled, the grid broadcast once from rank 0."""
+    line = _bench_two_ranks()
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2 and line["warmup"] == 1
+    cfg = line["config"]
+    assert cfg["baseline_config"] == 2 and cfg["views_per_gpu"] == 64 and cfg["images"] == 64
+    assert "broadcast" in cfg["parallelism"] and "gloo rehearsal" in cfg["parallelism"]
+    assert cfg["view_ranges"] == [[0, 64], [64, 128]]
+    assert line["metric"].startswith("novel views/sec") and line["unit"] == "views/s" and line["higher_is_better"] is True
+    assert line["value"] > 0 and abs(line["value"] - 128 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]   # both ranks' views
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1.0 and line["vs_baseline"] is None
