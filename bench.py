@@ -321,6 +321,8 @@ def main() -> int:
             return 2
         args.gpus = world
 
+    # the host driver of this pool supports dmabuf IPC only: RCCL's intra-node transport needs it (the image exports it already)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
