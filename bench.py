@@ -103,6 +103,7 @@ def timed(ctx, fn, iters: int, warm: int = 3, rounds: int = 3, warm_ms: float = 
 
 def also_table(L, device_index: int, iters: int, layout: str) -> dict:
     """The rest of BASELINE.json's configurations on ONE GPU, after the headline step (HIP-event times, inputs resident)."""
+    import numpy as np
     out = {}
 
     def entry(cfg, ms, views, kernel, note=None, flops_bound=None, n_images=None, in_bytes_extra=0.0):
@@ -242,6 +243,24 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
             out[key + "_render"] = entry(c5, ms_r, 64, k, "all-focus render from a resident focus map (structured light field)")
             out[key + "_end_to_end"] = entry(c5, ms_e, 64, "focus map + " + k, "lfi_focus_map + all-focus render per iteration (-r 0.17)",
                                              in_bytes_extra=map_in + map_io)
+        # BASELINE config 5 as the reference's focusMapCompare.sh uses it: a focus SWEEP over the resident light field — per step NEW parameters
+        # (lfi_set_params with another -f: stream-ordered upload, no synchronisation), the focus map, one all-focus render.  16 steps over
+        # -f 0.20 … 0.24 (around the focus the scene was built for), host parameter arithmetic outside the timed region.
+        sweep = [L.build_params(c5["cols"], c5["rows"], c5["W"], c5["H"], c5["traj"], f, c5["rng"], c5["effect"], c5["aspect"], c5["views"])
+                 for f in np.linspace(0.20, 0.24, 16)]
+
+        def sweep_pass():
+            for hp_f in sweep:
+                ctx.set_params(hp_f)
+                ctx.focus_map()
+                ctx.render("TEN_WM", all_focus=True)
+
+        sweep_pass()                                                           # the padded planes grow to the sweep's largest shift once
+        ms_sweep = timed(ctx, sweep_pass, 1, warm=1, rounds=3) / len(sweep)
+        out["config5_focus_sweep_step"] = entry(c5, ms_sweep, 64, "lfi_set_params + focus map + " + ctx.last_kernel_name(),
+                                                "per step of a 16-step focus sweep (-f 0.20 … 0.24): new parameters, focus map, all-focus TEN_WM render",
+                                                in_bytes_extra=map_in + map_io)
+        ctx.set_params(hp)
         ctx.set_variant("STD", "vfma")
         ms_r = timed(ctx, lambda: ctx.render("STD", all_focus=True), 2, warm=1, rounds=2)
         out["config5_allfocus_std_nontensor"] = entry(c5, ms_r, 64, ctx.last_kernel_name(), "all-focus render by the non-tensor wavefront kernel", flops_bound=True)

@@ -169,7 +169,11 @@ int lfi_fill_synthetic_images(lfi_ctx *ctx, uint32_t seed, int g0, int g1);
 int lfi_fill_synthetic_scene(lfi_ctx *ctx, uint32_t seed);
 
 /* ---- parameters: replaces loadGPUOffsets / loadGPUWeights / selectFocusMapViews / loadGPUConstants
- *      (src/interpolator.cu:139-154, 194-246) ------------------------------------------------------------------ */
+ *      (src/interpolator.cu:139-154, 194-246) ------------------------------------------------------------------
+ * The arrays are copied before the call returns (the caller's memory is free again).  A call that keeps the number of views (a focus
+ * sweep, another trajectory of the same length) replaces the device arrays IN STREAM ORDER through page-locked staging: renders already
+ * enqueued keep the parameters they were enqueued with, later ones see the new ones, and the context's stream is not drained.  A call
+ * that changes the number of views synchronises and reallocates. */
 int lfi_set_params(lfi_ctx *ctx, const lfi_params *params);
 /* Device layout of the rendered views.  LFI_LAYOUT_RGBA (default): [V][rows][W] RGBA8 dwords — the linear image of the
  * reference's 64 output surfaces.  LFI_LAYOUT_PLANAR_RGB (opt-in): alpha-free byte planes [V][3: R,G,B][rows][pitch] — the alpha

@@ -62,6 +62,13 @@ struct lfi_ctx
     bool have_params = false;
     int views_n = 0, k_pad = 0, v_pad = 0, n_focus_ids = 0;
     void *param_blob = nullptr; // one allocation holding all parameter arrays
+    size_t param_blob_bytes = 0;
+    // lfi_set_params with an unchanged blob size (a focus sweep, a new trajectory with as many views): the new arrays go through one of two
+    // page-locked staging buffers and a stream-ordered copy — no synchronisation, no allocation
+    uint8_t *param_staging[2] = {nullptr, nullptr};
+    size_t param_staging_bytes = 0;
+    hipEvent_t ev_param[2] = {nullptr, nullptr};
+    int param_slot = 0;
     size_t blob_off_w16 = 0, blob_weights_bytes = 0; // the four weight arrays inside the blob (what lfi_render_stream replaces per block)
     // lfi_render_stream: page-locked staging for two blocks' weight arrays, a second set of views, events
     uint8_t *stream_staging[2] = {nullptr, nullptr};
@@ -372,7 +379,22 @@ void free_params(lfi_ctx *c)
     if(c->param_blob)
         (void)hipFree(c->param_blob);
     c->param_blob = nullptr;
+    c->param_blob_bytes = 0;
     c->have_params = false;
+}
+
+void free_param_staging(lfi_ctx *c)
+{
+    for(int i = 0; i < 2; i++)
+    {
+        if(c->param_staging[i])
+            (void)hipHostFree(c->param_staging[i]);
+        c->param_staging[i] = nullptr;
+        if(c->ev_param[i])
+            (void)hipEventDestroy(c->ev_param[i]);
+        c->ev_param[i] = nullptr;
+    }
+    c->param_staging_bytes = 0;
 }
 
 void free_views(lfi_ctx *c)

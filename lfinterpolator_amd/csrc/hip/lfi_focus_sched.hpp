@@ -35,8 +35,11 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     // that the neighbouring steps of a focus sweep find them large enough.
     const bool pad_kept = ctx->grid_tracked && ctx->focus_ws && ctx->pad_version == ctx->grid_version && ctx->pad_ids == ctx->h_focus_ids &&
                           ctx->pad_radius[0] == rx && ctx->pad_radius[1] == ry && ctx->pad_shift[0] >= Sx && ctx->pad_shift[1] >= Sy;
-    Sx = pad_kept ? ctx->pad_shift[0] : (Sx + 7) / 8 * 8;
-    Sy = pad_kept ? ctx->pad_shift[1] : (Sy + 7) / 8 * 8;
+    // Planes that have to GROW (an ascending sweep) grow by a quarter more than asked for: every change of the geometry rebuilds the planes
+    // and may reallocate a workspace of gigabytes (≈ 80 ms per step when it happened on every step of a sweep).
+    auto padded = [](const int need, const int had) { return ((had > 0 && need > had ? need + need / 4 : need) + 7) / 8 * 8; };
+    Sx = pad_kept ? ctx->pad_shift[0] : padded(Sx, ctx->pad_shift[0]);
+    Sy = pad_kept ? ctx->pad_shift[1] : padded(Sy, ctx->pad_shift[1]);
     w.Px = Sx + rx;
     w.Py = Sy + ry;
     w.Wp = (w.Px + std::max(W + Sx + rx, w.We_p - rx + Sx) + 3) / 4 * 4;
@@ -67,7 +70,7 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     const size_t o_K = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * (size_t)H * W);
     const size_t o_deltas = carve(sizeof(int64_t) * lfi::FOCUS_STEPS * lfi::FOCUS_MAX_IDS);
     const size_t o_pad = carve(pad_bytes);
-    if(ctx->focus_ws_bytes != at)
+    if(ctx->focus_ws_bytes < at) // a larger workspace serves smaller geometries too
     {
         if(ctx->focus_ws)
             (void)hipFree(ctx->focus_ws);

@@ -76,6 +76,7 @@ int lfi_destroy(lfi_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     free_params(ctx);
+    free_param_staging(ctx);
     free_views(ctx);
     free_grid(ctx);
     if(ctx->ev0)
@@ -452,7 +453,6 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
         return fail(ctx, LFI_EINVAL, "lfi_params: more than 4096 views");
     if(int rc = bind(ctx))
         return rc;
-    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
     if(ctx->windowed)
         for(int g = 0; g < ctx->n; g++)
@@ -477,7 +477,40 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     const size_t off_w32t = off_w32 + sizeof(float) * (size_t)v_pad * k_pad;
     const size_t off_ids = off_w32t + sizeof(float) * (size_t)v_pad * k_pad;
     const size_t total = off_ids + sizeof(int32_t) * LFI_MAX_FOCUS_IDS;
-    std::vector<uint8_t> blob(total, 0);
+    // Same blob size as the arrays in place (and as many views: nothing else to reallocate): stage in page-locked memory and copy in
+    // stream order — launches already enqueued keep reading the old arrays, later ones see the new; the context's stream is not
+    // drained.  Otherwise (first call, another view count or grid): synchronise, reallocate, copy synchronously.
+    const bool in_place = ctx->param_blob && ctx->param_blob_bytes == total && !views_changed && ctx->views;
+    std::vector<uint8_t> blob_pageable;
+    uint8_t *blob_ptr = nullptr;
+    if(in_place)
+    {
+        if(ctx->param_staging_bytes != total)
+        {
+            free_param_staging(ctx);
+            for(int i = 0; i < 2; i++)
+            {
+                LFI_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->param_staging[i]), total, hipHostMallocDefault));
+                LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_param[i], hipEventDisableTiming));
+            }
+            ctx->param_staging_bytes = total;
+        }
+        else
+            LFI_HIP(ctx, hipEventSynchronize(ctx->ev_param[ctx->param_slot])); // the copy out of this buffer, two calls ago, has run
+        blob_ptr = ctx->param_staging[ctx->param_slot];
+        std::memset(blob_ptr, 0, total);
+    }
+    else
+    {
+        LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        blob_pageable.assign(total, 0);
+        blob_ptr = blob_pageable.data();
+    }
+    struct
+    {
+        uint8_t *p;
+        uint8_t *data() const { return p; }
+    } blob{blob_ptr};
     std::memcpy(blob.data() + off_focused, p->focused_offsets, sizeof(lfi_int2) * n);
     int fo_min[2] = {p->focused_offsets[0].x, p->focused_offsets[0].y}, fo_max[2] = {fo_min[0], fo_min[1]};
     for(int g = 1; g < n; g++)
@@ -494,9 +527,19 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     if(p->n_focus_ids)
         std::memcpy(blob.data() + off_ids, p->focus_map_ids, sizeof(int32_t) * p->n_focus_ids);
 
-    free_params(ctx);
-    LFI_HIP(ctx, hipMalloc(&ctx->param_blob, total));
-    LFI_HIP(ctx, hipMemcpy(ctx->param_blob, blob.data(), total, hipMemcpyHostToDevice));
+    if(in_place)
+    {
+        LFI_HIP(ctx, hipMemcpyAsync(ctx->param_blob, blob.data(), total, hipMemcpyHostToDevice, ctx->stream));
+        LFI_HIP(ctx, hipEventRecord(ctx->ev_param[ctx->param_slot], ctx->stream));
+        ctx->param_slot ^= 1;
+    }
+    else
+    {
+        free_params(ctx);
+        LFI_HIP(ctx, hipMalloc(&ctx->param_blob, total));
+        ctx->param_blob_bytes = total;
+        LFI_HIP(ctx, hipMemcpy(ctx->param_blob, blob.data(), total, hipMemcpyHostToDevice));
+    }
     uint8_t *base = static_cast<uint8_t *>(ctx->param_blob);
     ctx->d_focused = reinterpret_cast<lfi_int2 *>(base + off_focused);
     ctx->d_offsets = reinterpret_cast<lfi_float2 *>(base + off_offsets);

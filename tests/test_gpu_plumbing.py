@@ -395,3 +395,50 @@ def test_prepare_memory_info_and_partial_fills(gpu, oracle_c):
     ctx.sync()
     assert len(np.unique(ctx.download_map(0)[..., 0])) >= 1
     ctx.close()
+
+
+def test_set_params_in_place_is_stream_ordered(gpu, oracle_c):
+    """lfi_set_params with an unchanged array size (a focus sweep) uploads in stream order without draining the stream: a render already
+    enqueued keeps its parameters, the next one sees the new ones — over more calls than there are staging buffers, for both methods, and
+    for the focus map + all-focus render of each step."""
+    cols = rows = 8
+    W, H, V = 640, 120, 64
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, SEED)
+    foci = [0.05, 0.23, 0.4, 0.11, 0.3]
+    hps = [gpu.build_params(cols, rows, W, H, "0,0,1,1", f, 0.0, 3.0, 1.783, V) for f in foci]
+    want = [oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, threads=8) for hp in hps]
+    assert not (want[0] == want[1]).all()
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.upload_grid(lf)
+    ctx.set_params(hps[0])
+    for i in range(len(hps)):
+        ctx.render("STD")                                   # enqueued with hps[i] …
+        ctx.set_params(hps[(i + 1) % len(hps)])             # … and NOT waited for: the next parameters are on their way behind it
+        got = ctx.download_views()                          # (synchronises)
+        assert (got == want[i]).all(), (i, int((got != want[i]).sum()))
+    # TEN_WM after the sweep came round: the first parameters again
+    ctx.render("TEN_WM")
+    ctx.sync()
+    m16 = oracle_c.blend_ten(lf, hps[0].focused_offsets, hps[0].offsets, hps[0].weights, model=oracle_c.TEN_M16, threads=8)
+    assert np.abs(ctx.download_views().astype(int) - m16.astype(int)).max() <= 1
+    ctx.close()
+    # the sweep with focus maps: every step's map and all-focus render against the oracle, parameters replaced without a wait in between
+    W2, H2, V2 = 200, 40, 8
+    lf2 = (oracle_c.synthetic_lf(cols * rows, W2, H2, SEED + 1) // 32 * 32).astype(np.uint8)
+    lf2[..., 3] = 255
+    sw = [gpu.build_params(cols, rows, W2, H2, "0.071,0.071,0.93,0.93", f, 0.17, 3.0, 1.783, V2) for f in (0.1, 0.22, 0.3, 0.15)]
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W2, H2)
+    ctx.upload_grid(lf2)
+    ctx.set_params(sw[0])
+    for i, hp in enumerate(sw):
+        ctx.focus_map()
+        ctx.render("STD", all_focus=True)
+        ctx.set_params(sw[(i + 1) % len(sw)])
+        map0 = oracle_c.focus_estimate(lf2, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, threads=8)
+        map1 = oracle_c.focus_filter(map0, hp.block_radius)
+        assert (ctx.download_map(0) == map0).all() and (ctx.download_map(1) == map1).all(), i
+        ref = oracle_c.blend_std(lf2, hp.focused_offsets, hp.offsets, hp.weights, all_focus=True, map_plane=map1, focus=hp.focus, rng=hp.range, threads=8)
+        assert (ctx.download_views() == ref).all(), i
+    ctx.close()
