@@ -288,7 +288,9 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     };
     if(valid && (!tune || tuned()))
         return true;
-    const int built_for = std::max(reach, c->planar_reach);
+    // a copy that has to GROW (a sweep towards larger offsets) is padded for a quarter more than asked for: every growth is a rebuild, and
+    // a reallocation of up to gigabytes if the planes no longer fit the allocation
+    const int built_for = c->planar && reach > c->planar_reach ? reach + reach / 4 + 8 : std::max(reach, c->planar_reach);
     const int padx = (built_for + 3) / 4 * 4;
     const int tiles_w = (c->width + 127) / 128 * 128;
     int pitch = (padx + 3 + tiles_w + built_for + 15) / 16 * 16; // + 3: the largest phase
@@ -301,7 +303,7 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     if(c->in_rows >= (1 << 24) || pitch >= (1 << 24) || (uint64_t)26 * c->in_rows * pitch >= (1ull << 32))
         return false;
     const size_t bytes = (size_t)c->n * 3 * c->in_rows * pitch; // the rows this context holds (a row window: band + halo)
-    if(bytes != c->planar_bytes)
+    if(bytes > c->planar_bytes) // (a larger allocation serves smaller planes too)
     {
         if(c->planar)
             (void)hipFree(c->planar);
