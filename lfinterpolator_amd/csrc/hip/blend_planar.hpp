@@ -37,13 +37,14 @@ namespace lfi {
 
 // grid (ceil(pitch/1024), H, N): a thread writes one dword (4 consecutive bytes) of the 3 planes of its image row
 // H = rows HELD per plane (the whole image, or the input rows of a row window)
+// g0: the first image of the range this launch converts (gridDim.z images: all of them, or the ones that changed)
 __global__ void __launch_bounds__(256) planar_build(const uint8_t *__restrict__ grid, uint8_t *__restrict__ planar, const int W, const int H,
-                                                    const int pitch, const int padx, const int32_t *__restrict__ phase)
+                                                    const int pitch, const int padx, const int32_t *__restrict__ phase, const int g0)
 {
     const int j4 = (blockIdx.x * 256 + threadIdx.x) * 4; // first byte column of this thread's dword
     if(j4 >= pitch)
         return;
-    const int y = blockIdx.y, g = blockIdx.z;
+    const int y = blockIdx.y, g = g0 + blockIdx.z;
     const uint32_t *row = reinterpret_cast<const uint32_t *>(grid) + ((size_t)g * H + y) * W;
     const int first = padx + phase[g]; // byte of pixel 0
     uint32_t px[4]; // byte j of a plane row holds pixel j − first, edges replicated

@@ -101,12 +101,13 @@ __global__ void __launch_bounds__(1024) focus_plan_shifts(const KernelArgs a, co
 }
 
 // pad[k][yy][xx] = I_ids[k][clamp(yy − Py)][clamp(xx − Px)]; grid (ceil(Wp/256), Hp, n_ids), a lane writes 4 pixels
-__global__ void __launch_bounds__(64) focus_pad(const KernelArgs a, const FocusWork w)
+// k0: the first sampled image of the range this launch pads (gridDim.z of them: all, or the ones that changed)
+__global__ void __launch_bounds__(64) focus_pad(const KernelArgs a, const FocusWork w, const int k0)
 {
     const int xx = (blockIdx.x * 64 + threadIdx.x) * 4;
     if(xx >= w.Wp)
         return;
-    const int yy = blockIdx.y, k = blockIdx.z;
+    const int yy = blockIdx.y, k = k0 + blockIdx.z;
     const int W = a.width, H = a.height;
     const uint32_t *row = reinterpret_cast<const uint32_t *>(a.grid) + (size_t)a.focus_ids[k] * ((size_t)W * H) +
                           (size_t)clampi(yy - w.Py, 0, H - 1) * W;

@@ -102,6 +102,11 @@ struct lfi_ctx
     std::vector<lfi_int2> h_focused;        // the integer offsets of the current parameters (host copy)
     unsigned launches_with_offsets = 0;     // fixed-focus launches since the integer offsets last changed
     uint64_t grid_version = 1, planar_version = 0;
+    // which images changed: grid_full_version = grid_version at the last change that may have touched every image; img_version[g] = at the
+    // last change of image g alone (lfi_upload_image[_async], lfi_fill_synthetic_images).  A derived copy brought up to date at version v
+    // holds image g's current pixels iff max(img_version[g], grid_full_version) ≤ v: one replaced image costs one image's planes.
+    uint64_t grid_full_version = 1;
+    std::vector<uint64_t> img_version;
     bool grid_tracked = true; // every write to the planes goes through this library (or is announced by lfi_grid_modified)
     void *focus_ws = nullptr; // workspace of the factored focus-map estimate (plan, E, K), allocated on first use
     size_t focus_ws_bytes = 0;
@@ -372,6 +377,30 @@ void fill_weight_arrays(const uint16_t *weights_fp16, int rows, int n, int k_pad
     }
     *scalable_out = scalable;
     *sums_ok_out = sums_ok;
+}
+
+// every image may have changed / images [g0, g1) changed
+void touch_all(lfi_ctx *c)
+{
+    c->grid_full_version = ++c->grid_version;
+}
+
+void touch_images(lfi_ctx *c, int g0, int g1)
+{
+    ++c->grid_version;
+    if((int)c->img_version.size() != c->n)
+    {
+        c->img_version.assign(c->n, 0);
+        c->grid_full_version = c->grid_version; // no per-image record yet
+        return;
+    }
+    for(int g = g0; g < g1; g++)
+        c->img_version[g] = c->grid_version;
+}
+
+bool image_changed_since(const lfi_ctx *c, int g, uint64_t version)
+{
+    return c->grid_full_version > version || (int)c->img_version.size() != c->n || c->img_version[g] > version;
 }
 
 void free_params(lfi_ctx *c)

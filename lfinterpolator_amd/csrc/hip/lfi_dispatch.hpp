@@ -288,6 +288,30 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     };
     if(valid && (!tune || tuned()))
         return true;
+    // the copy in place fits and only SOME images were replaced since it was brought up to date (lfi_upload_image, a partial fill): their
+    // planes only — 1/N of a rebuild per image
+    if(c->planar && c->planar_version != 0 && c->planar_reach >= reach && (int)c->planar_phase.size() == c->n &&
+       c->grid_full_version <= c->planar_version && (!tune || tuned()))
+    {
+        for(int g = 0; g < c->n;)
+        {
+            if(!image_changed_since(c, g, c->planar_version))
+            {
+                g++;
+                continue;
+            }
+            int g1 = g + 1;
+            while(g1 < c->n && image_changed_since(c, g1, c->planar_version))
+                g1++;
+            hipLaunchKernelGGL(lfi::planar_build, dim3((c->planar_pitch / 4 + 255) / 256, c->in_rows, g1 - g), dim3(256), 0, c->stream, c->grid,
+                               c->planar, c->width, c->in_rows, c->planar_pitch, c->planar_padx, c->d_planar_phase, g);
+            g = g1;
+        }
+        if(hipGetLastError() != hipSuccess)
+            return false;
+        c->planar_version = c->grid_version;
+        return true;
+    }
     // a copy that has to GROW (a sweep towards larger offsets) is padded for a quarter more than asked for: every growth is a rebuild, and
     // a reallocation of up to gigabytes if the planes no longer fit the allocation
     const int built_for = c->planar && reach > c->planar_reach ? reach + reach / 4 + 8 : std::max(reach, c->planar_reach);
@@ -337,7 +361,7 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     c->planar_reach = built_for;
     c->planar_pitch = pitch;
     hipLaunchKernelGGL(lfi::planar_build, dim3((pitch / 4 + 255) / 256, c->in_rows, c->n), dim3(256), 0, c->stream, c->grid, c->planar,
-                       c->width, c->in_rows, pitch, padx, c->d_planar_phase);
+                       c->width, c->in_rows, pitch, padx, c->d_planar_phase, 0);
     if(hipGetLastError() != hipSuccess)
         return false;
     c->planar_version = c->grid_version;

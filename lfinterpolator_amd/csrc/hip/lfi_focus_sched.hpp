@@ -33,8 +33,10 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     // The padded planes of an earlier call serve this one if the inputs have not changed since and their padding covers these shifts
     // (any larger padding gives the same samples): then the geometry is theirs.  New planes are padded to the next multiple of 8, so
     // that the neighbouring steps of a focus sweep find them large enough.
-    const bool pad_kept = ctx->grid_tracked && ctx->focus_ws && ctx->pad_version == ctx->grid_version && ctx->pad_ids == ctx->h_focus_ids &&
-                          ctx->pad_radius[0] == rx && ctx->pad_radius[1] == ry && ctx->pad_shift[0] >= Sx && ctx->pad_shift[1] >= Sy;
+    // (also when only SOME images were replaced since — lfi_upload_image —: then only the planes of the sampled images among them are redone)
+    const bool pad_kept = ctx->grid_tracked && ctx->focus_ws && ctx->pad_version != 0 && ctx->grid_full_version <= ctx->pad_version &&
+                          ctx->pad_ids == ctx->h_focus_ids && ctx->pad_radius[0] == rx && ctx->pad_radius[1] == ry && ctx->pad_shift[0] >= Sx &&
+                          ctx->pad_shift[1] >= Sy;
     // Planes that have to GROW (an ascending sweep) grow by a quarter more than asked for: every change of the geometry rebuilds the planes
     // and may reallocate a workspace of gigabytes (≈ 80 ms per step when it happened on every step of a sweep).
     auto padded = [](const int need, const int had) { return ((had > 0 && need > had ? need + need / 4 : need) + 7) / 8 * 8; };
@@ -118,9 +120,16 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     // host launch order = the critical path first: the main stream's kernels are enqueued before the side stream's
     hipLaunchKernelGGL(lfi::focus_plan_shifts, dim3(1), dim3(1024), 0, st, a, w);
     LFI_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
-    if(!(pad_kept && ctx->pad_version == ctx->grid_version)) // (a reallocated workspace cleared pad_version)
+    if(pad_kept && ctx->pad_version != 0) // (a reallocated workspace cleared pad_version)
     {
-        hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, ctx->n_focus_ids), dim3(64), 0, st, a, w);
+        for(int k = 0; k < ctx->n_focus_ids; k++)
+            if(image_changed_since(ctx, ctx->h_focus_ids[k], ctx->pad_version))
+                hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, 1), dim3(64), 0, st, a, w, k);
+        ctx->pad_version = ctx->grid_version;
+    }
+    else
+    {
+        hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, ctx->n_focus_ids), dim3(64), 0, st, a, w, 0);
         ctx->pad_version = ctx->grid_tracked ? ctx->grid_version : 0;
         ctx->pad_shift[0] = Sx;
         ctx->pad_shift[1] = Sy;

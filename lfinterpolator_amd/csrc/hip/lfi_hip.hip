@@ -170,7 +170,7 @@ int lfi_set_grid(lfi_ctx *ctx, int cols, int rows, int width, int height)
     ctx->grid_bytes = plane_bytes(ctx) * ctx->n;
     LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->grid), ctx->grid_bytes));
     ctx->own_grid = true;
-    ctx->grid_version++;
+    touch_all(ctx);
     ctx->grid_tracked = true;
     LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->maps), plane_bytes(ctx) * 2));
     LFI_HIP(ctx, hipMemsetAsync(ctx->maps, 0, plane_bytes(ctx) * 2, ctx->stream));
@@ -205,7 +205,7 @@ int lfi_set_row_window(lfi_ctx *ctx, int out_y0, int out_y1, int in_y0, int in_y
     ctx->grid_bytes = in_plane_bytes(ctx) * ctx->n;
     LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->grid), ctx->grid_bytes));
     ctx->own_grid = true;
-    ctx->grid_version++;
+    touch_all(ctx);
     ctx->grid_tracked = true;
     return LFI_OK;
 }
@@ -226,7 +226,7 @@ int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_byte
     LFI_HIP(ctx, hipMemcpy2DAsync(ctx->grid + in_plane_bytes(ctx) * g, (size_t)ctx->width * 4, rgba + (size_t)ctx->in_y0 * pitch_bytes,
                                   pitch_bytes, (size_t)ctx->width * 4, ctx->in_rows, hipMemcpyHostToDevice, ctx->stream));
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->grid_version++;
+    touch_images(ctx, g, g + 1);
     return LFI_OK;
 }
 
@@ -256,7 +256,7 @@ int lfi_upload_image_async(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitc
     LFI_HIP(ctx, hipMemcpy2DAsync(ctx->grid + in_plane_bytes(ctx) * g, row_bytes, rgba + (size_t)ctx->in_y0 * pitch_bytes, pitch_bytes, row_bytes,
                                   ctx->in_rows, hipMemcpyHostToDevice, ctx->copy_stream));
     ctx->uploads_pending = true;
-    ctx->grid_version++;
+    touch_images(ctx, g, g + 1);
     return LFI_OK;
 }
 
@@ -293,7 +293,7 @@ int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes)
     ctx->grid = static_cast<uint8_t *>(device_ptr);
     ctx->own_grid = false;
     ctx->grid_bytes = bytes;
-    ctx->grid_version++;
+    touch_all(ctx);
     ctx->grid_tracked = false; // the caller writes this buffer itself: see lfi_grid_modified
     return LFI_OK;
 }
@@ -363,7 +363,7 @@ int lfi_broadcast_grid(lfi_ctx *const *ctxs, int n, int root)
     for(int i = 0; i < n; i++)
     {
         (void)nc.CommDestroy(comms[i]);
-        ctxs[i]->grid_version++;
+        touch_all(ctxs[i]);
     }
     if(caller_device >= 0)
         (void)hipSetDevice(caller_device);
@@ -380,7 +380,7 @@ int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes)
     if(out_bytes)
         *out_bytes = ctx->grid ? in_plane_bytes(ctx) * ctx->n : 0;
     ctx->grid_tracked = false; // the caller may write through the pointer: see lfi_grid_modified
-    ctx->grid_version++;
+    touch_all(ctx);
     return LFI_OK;
 }
 
@@ -390,7 +390,7 @@ int lfi_grid_modified(lfi_ctx *ctx)
         return LFI_EINVAL;
     if(!ctx->grid)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
-    ctx->grid_version++;
+    touch_all(ctx);
     ctx->grid_tracked = true; // the caller announces its writes from now on
     return LFI_OK;
 }
@@ -409,7 +409,7 @@ int lfi_fill_synthetic_images(lfi_ctx *ctx, uint32_t seed, int g0, int g1)
         return rc;
     if(int rc = join_uploads(ctx))
         return rc;
-    ctx->grid_version++;
+    touch_images(ctx, g0, g1);
     hipLaunchKernelGGL(lfi::fill_synthetic, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, g0, g1 - g0, ctx->width,
                        ctx->in_rows, ctx->in_y0, seed);
     LFI_HIP(ctx, hipGetLastError());
@@ -424,7 +424,7 @@ int lfi_fill_synthetic_scene(lfi_ctx *ctx, uint32_t seed)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid / lfi_set_params have not been called (the scene is built from the images' offsets)");
     if(int rc = bind(ctx))
         return rc;
-    ctx->grid_version++;
+    touch_all(ctx);
     hipLaunchKernelGGL(lfi::fill_scene, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, ctx->d_offsets, ctx->n, ctx->width, ctx->in_rows,
                        ctx->in_y0, seed, ctx->focus, ctx->range);
     LFI_HIP(ctx, hipGetLastError());

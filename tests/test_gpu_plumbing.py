@@ -442,3 +442,51 @@ def test_set_params_in_place_is_stream_ordered(gpu, oracle_c):
         ref = oracle_c.blend_std(lf2, hp.focused_offsets, hp.offsets, hp.weights, all_focus=True, map_plane=map1, focus=hp.focus, rng=hp.range, threads=8)
         assert (ctx.download_views() == ref).all(), i
     ctx.close()
+
+
+def test_replaced_images_refresh_only_their_planes(gpu, oracle_c):
+    """One or a few images replaced (lfi_upload_image, asynchronous uploads, a partial device fill): the derived planar copy and the
+    focus map's padded planes are refreshed for THOSE images only — every render and map must still be the oracle's for the mixed light
+    field, in both view layouts, with first / last / neighbouring / scattered images replaced."""
+    cols, rows, W, H, V = 5, 3, 200, 24, 8
+    n = cols * rows
+    hp = gpu.build_params(cols, rows, W, H, "0.1,0.2,0.8,0.9", 0.25, 0.17, 2.0, 1.5, V)
+    lf = (oracle_c.synthetic_lf(n, W, H, 11) // 16 * 16).astype(np.uint8)
+    lf[..., 3] = 255
+    other = (oracle_c.synthetic_lf(n, W, H, 12) // 16 * 16).astype(np.uint8)
+    other[..., 3] = 255
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.upload_grid(lf)
+    ctx.set_params(hp)
+
+    def check(cur, what):
+        for layout in ("rgba", "planar"):
+            ctx.set_output_layout(layout)
+            ctx.render("STD"); ctx.sync()
+            assert (ctx.download_views() == oracle_c.blend_std(cur, hp.focused_offsets, hp.offsets, hp.weights, threads=8)).all(), (what, layout, "STD")
+            ctx.render("TEN_WM"); ctx.sync()
+            m16 = oracle_c.blend_ten(cur, hp.focused_offsets, hp.offsets, hp.weights, model=oracle_c.TEN_M16, threads=8)
+            assert np.abs(ctx.download_views().astype(int) - m16.astype(int)).max() <= 1, (what, layout, "TEN_WM")
+        ctx.set_output_layout("rgba")
+        ctx.focus_map(); ctx.sync()
+        map0 = oracle_c.focus_estimate(cur, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, threads=8)
+        assert (ctx.download_map(0) == map0).all(), (what, "map")
+
+    cur = lf.copy()
+    check(cur, "initial")
+    sampled = [int(g) for g in hp.focus_map_ids]
+    unsampled = [g for g in range(n) if g not in sampled]
+    for what, ids, asynchronous in (("first image", [0], False), ("last image", [n - 1], False), ("two neighbours", [6, 7], False),
+                                    ("scattered, asynchronous", [1, 5, 9, 13], True), ("a sampled image", sampled[:1], False),
+                                    ("an image the map does not sample", unsampled[:1], True)):
+        if not ids:
+            continue
+        for g in ids:
+            cur[g] = other[g] if (cur[g] == lf[g]).all() else lf[g]
+            (ctx.upload_image_async if asynchronous else ctx.upload_image)(g, cur[g])
+        check(cur, what)
+    ctx.fill_synthetic(0x55, 4, 9)                       # a partial fill on the device: images 4 … 8
+    cur[4:9] = oracle_c.synthetic_lf(n, W, H, 0x55)[4:9]
+    check(cur, "partial fill")
+    ctx.close()
