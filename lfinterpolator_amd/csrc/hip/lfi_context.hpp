@@ -11,7 +11,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <string>
 #include <vector>
 
@@ -98,7 +97,10 @@ struct lfi_ctx
     size_t planar_bytes = 0;
     int planar_pitch = 0, planar_padx = 0, planar_reach = 0; // bytes per plane row; left padding; the largest |x offset| it was built for
     int32_t *d_planar_phase = nullptr;      // [LFI_MAX_IMAGES] per-image phase of the planar copy (device)
-    std::vector<int32_t> planar_phase;      // the same on the host (kept alive: the upload is asynchronous)
+    std::vector<int32_t> planar_phase;      // the same on the host
+    int32_t *phase_staging = nullptr;       // page-locked, 2 × LFI_MAX_IMAGES: a rebuild's phases go to the device in stream order, no host wait
+    hipEvent_t ev_phase[2] = {nullptr, nullptr};
+    int phase_slot = 0;
     std::vector<lfi_int2> h_focused;        // the integer offsets of the current parameters (host copy)
     unsigned launches_with_offsets = 0;     // fixed-focus launches since the integer offsets last changed
     uint64_t grid_version = 1, planar_version = 0;
@@ -125,75 +127,21 @@ struct lfi_ctx
 
 namespace {
 
-// The context's own views in the planar layout live in UNCACHED device memory: they are write-only for the renders (full 128-byte
-// lines, non-temporal stores), and planes that bypass the caches leave more of the Infinity Cache to the inputs the next launch
-// re-reads (tools/views_mtype.py, config 2: 150 µs against 156 µs per launch).  RGBA views stay in ordinary memory (the STD band
-// epilogue patches single bytes behind its dword stores).  Measurement builds: LFI_VIEWS_MEMORY=default|uncached|finegrained overrides.
-//
-// Uncached blocks are NEVER handed back to the HIP runtime while the process lives (round 3).  Freed with hipFree, their address range
-// is recycled for later ordinary allocations — and contexts created after a few such cycles rendered garbage from ordinary memory
-// (inputs, parameters or RGBA views landing on a range that had been uncached: `tools/dbg_ragged.py`, reproduced three times out of
-// three with uncached views, never with ordinary or fine-grained ones; found when the view pitch changed the allocation sizes and the
-// planar row-band tests started to fail).  So released blocks go to a process-wide free list and are only ever reused as uncached views.
-struct UncachedBlock
-{
-    void *ptr;
-    size_t bytes;
-    int device;
-    bool in_use;
-};
-std::mutex g_uncached_mutex;
-std::vector<UncachedBlock> g_uncached_blocks;
-
-hipError_t uncached_alloc(uint8_t **out, size_t bytes, int device)
-{
-    std::lock_guard<std::mutex> lock(g_uncached_mutex);
-    UncachedBlock *best = nullptr;
-    for(UncachedBlock &b : g_uncached_blocks)
-        if(!b.in_use && b.device == device && b.bytes >= bytes && (!best || b.bytes < best->bytes))
-            best = &b;
-    if(best)
-    {
-        best->in_use = true;
-        *out = static_cast<uint8_t *>(best->ptr);
-        return hipSuccess;
-    }
-    void *p = nullptr;
-    const hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
-    if(e != hipSuccess)
-        return e;
-    g_uncached_blocks.push_back(UncachedBlock{p, bytes, device, true});
-    *out = static_cast<uint8_t *>(p);
-    return hipSuccess;
-}
-
-bool uncached_release(void *p) // true: p was one of ours (kept for reuse); false: an ordinary allocation, the caller frees it
-{
-    std::lock_guard<std::mutex> lock(g_uncached_mutex);
-    for(UncachedBlock &b : g_uncached_blocks)
-        if(b.ptr == p)
-        {
-            b.in_use = false;
-            return true;
-        }
-    return false;
-}
-
-hipError_t alloc_views(uint8_t **out, size_t bytes, bool planar_layout, int device)
+// Every allocation of the views is ordinary device memory (hipMalloc) and goes back to the runtime with hipFree.  Rounds 2-3 placed the
+// library's own planar views in hipDeviceMallocUncached memory (write-only planes that bypass the caches: -3.5 % at config 2 in round 2) and
+// then had to keep every such block alive for the whole process, because contexts created after freed uncached ranges had been recycled as
+// ordinary memory rendered garbage (profiles/r03_notes.md section 6).  Round 3's own A/B (profiles/r03_views_memory_ab.txt) shows no gain
+// left from the placement outside box noise, so round 4 removed it together with the immortal pool: no allocation outlives its context.
+// Measurement builds (tools/views_mtype.py): LFI_VIEWS_MEMORY=uncached|finegrained still selects the other kinds for A/B runs.
+hipError_t alloc_views(uint8_t **out, size_t bytes)
 {
 #ifdef LFI_MEASUREMENT_BUILD
-    static const int forced = [] {
-        const char *e = std::getenv("LFI_VIEWS_MEMORY");
-        return !e ? -1 : (std::strcmp(e, "uncached") == 0 ? 1 : (std::strcmp(e, "finegrained") == 0 ? 2 : 0));
-    }();
-#else
-    constexpr int forced = -1;
-#endif
-    const int kind = forced >= 0 ? forced : (planar_layout ? 1 : 0);
-    if(kind == 1)
-        return uncached_alloc(out, bytes, device);
-    if(kind == 2)
+    const char *e = std::getenv("LFI_VIEWS_MEMORY");
+    if(e && std::strcmp(e, "uncached") == 0)
+        return hipExtMallocWithFlags(reinterpret_cast<void **>(out), bytes, hipDeviceMallocUncached);
+    if(e && std::strcmp(e, "finegrained") == 0)
         return hipExtMallocWithFlags(reinterpret_cast<void **>(out), bytes, hipDeviceMallocFinegrained);
+#endif
     return hipMalloc(reinterpret_cast<void **>(out), bytes);
 }
 
@@ -428,7 +376,7 @@ void free_param_staging(lfi_ctx *c)
 
 void free_views(lfi_ctx *c)
 {
-    if(c->own_views && c->views && !uncached_release(c->views))
+    if(c->own_views && c->views)
         (void)hipFree(c->views);
     c->views = nullptr;
     c->own_views = false;
@@ -477,6 +425,15 @@ void free_grid(lfi_ctx *c)
     if(c->d_planar_phase)
         (void)hipFree(c->d_planar_phase);
     c->d_planar_phase = nullptr;
+    if(c->phase_staging)
+        (void)hipHostFree(c->phase_staging);
+    c->phase_staging = nullptr;
+    for(int i = 0; i < 2; i++)
+    {
+        if(c->ev_phase[i])
+            (void)hipEventDestroy(c->ev_phase[i]);
+        c->ev_phase[i] = nullptr;
+    }
 }
 
 } // namespace

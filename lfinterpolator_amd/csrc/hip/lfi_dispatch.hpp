@@ -249,6 +249,8 @@ int check_render_args(lfi_ctx *c, int method, int v0, int v1)
         return fail(c, LFI_EINVAL, "The specified interpolation method does not exist!");
     if(v0 < 0 || v1 > c->views_n || v0 >= v1)
         return fail(c, LFI_EINVAL, "view range [v0, v1) outside [0, views)");
+    if(!c->views)
+        return fail(c, LFI_EINVAL, "the context has no view buffer (a failed allocation: lfi_set_params again)");
     return LFI_OK;
 }
 
@@ -348,15 +350,31 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
         c->d_planar_phase = nullptr;
         return false;
     }
-    // the phases: (offset + padx + phase) ≡ 0 mod 4 for the offsets in use now.  Synchronous upload of ≤ 1 KB: kernels of earlier
-    // launches that read the old phases are ordered before it on the stream, and the host vector may change right after.
-    c->planar_phase.assign(c->n, 0);
-    for(int g = 0; g < c->n; g++)
-        c->planar_phase[g] = (4 - ((c->h_focused[g].x + padx) & 3)) & 3;
-    c->planar_version = 0;
-    if(hipMemcpyAsync(c->d_planar_phase, c->planar_phase.data(), sizeof(int32_t) * c->n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-       hipStreamSynchronize(c->stream) != hipSuccess)
+    // the phases: (offset + padx + phase) ≡ 0 mod 4 for the offsets in use now.  They travel through one of two page-locked buffers and a
+    // stream-ordered copy (as lfi_set_params' blob does): kernels of earlier launches that read the old phases are ordered before the
+    // copy, the build and every later launch after it, and the host never waits for the stream (round 3 copied from a pageable vector
+    // and synchronised the stream inside lfi_render).
+    if(!c->phase_staging)
+    {
+        if(hipHostMalloc(reinterpret_cast<void **>(&c->phase_staging), sizeof(int32_t) * 2 * LFI_MAX_IMAGES, hipHostMallocDefault) != hipSuccess ||
+           hipEventCreateWithFlags(&c->ev_phase[0], hipEventDisableTiming) != hipSuccess ||
+           hipEventCreateWithFlags(&c->ev_phase[1], hipEventDisableTiming) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    else if(hipEventSynchronize(c->ev_phase[c->phase_slot]) != hipSuccess) // the copy out of this buffer, two rebuilds ago, has run
         return false;
+    c->planar_phase.assign(c->n, 0);
+    int32_t *staged = c->phase_staging + (size_t)c->phase_slot * LFI_MAX_IMAGES;
+    for(int g = 0; g < c->n; g++)
+        staged[g] = c->planar_phase[g] = (4 - ((c->h_focused[g].x + padx) & 3)) & 3;
+    c->planar_version = 0;
+    if(hipMemcpyAsync(c->d_planar_phase, staged, sizeof(int32_t) * c->n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+       hipEventRecord(c->ev_phase[c->phase_slot], c->stream) != hipSuccess)
+        return false;
+    c->phase_slot ^= 1;
     c->planar_padx = padx;
     c->planar_reach = built_for;
     c->planar_pitch = pitch;
@@ -368,10 +386,14 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     return true;
 }
 
-// launch_blend's policy for the rebuild above: the same integer offsets rendered for the third time
+// launch_blend's policy for the rebuild above.  A rebuild re-converts the whole copy (0.25 ms at config 2, ≈ 3 ms at config 5) for a 3–5 %
+// gain per launch: it pays for itself after ≈ 40 launches.  So a render only retunes once the same integer offsets have been rendered
+// LFI_RETUNE_AFTER times (the reference's own loop is 100 launches over one parameter set, src/interpolator.cu:270-295; round 3 retuned
+// at the third launch, a net loss for short runs); lfi_prepare and lfi_benchmark retune at once, outside any render.
+constexpr unsigned LFI_RETUNE_AFTER = 32;
 bool tune_planar_now(lfi_ctx *c)
 {
-    return c->launches_with_offsets++ >= 2;
+    return c->launches_with_offsets++ >= LFI_RETUNE_AFTER;
 }
 
 // Would this launch read the planar copy of the inputs?  It pays where reads are a large share of the traffic: not for launches

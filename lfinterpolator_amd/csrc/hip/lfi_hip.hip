@@ -582,7 +582,8 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
         {
             free_views(ctx);
             ctx->views_bytes = out_plane_bytes(ctx) * V;
-            LFI_HIP(ctx, alloc_views(&ctx->views, ctx->views_bytes, ctx->out_layout == LFI_LAYOUT_PLANAR_RGB, ctx->device));
+            ctx->have_params = false; // until the views exist: a failed allocation must not leave renders a null pointer to store through
+            LFI_HIP(ctx, alloc_views(&ctx->views, ctx->views_bytes));
             ctx->own_views = true;
         }
     }
@@ -627,8 +628,10 @@ int lfi_set_output_layout(lfi_ctx *ctx, int layout)
     if(ctx->have_params)
     {
         ctx->views_bytes = out_plane_bytes(ctx) * ctx->views_n;
-        LFI_HIP(ctx, alloc_views(&ctx->views, ctx->views_bytes, ctx->out_layout == LFI_LAYOUT_PLANAR_RGB, ctx->device));
+        ctx->have_params = false; // a failed allocation leaves the context without parameters (lfi_set_params again), not with null views
+        LFI_HIP(ctx, alloc_views(&ctx->views, ctx->views_bytes));
         ctx->own_views = true;
+        ctx->have_params = true;
     }
     return LFI_OK;
 }
