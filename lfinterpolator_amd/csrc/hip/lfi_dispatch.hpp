@@ -12,6 +12,7 @@
 #include "blend_p3.hpp"
 #include "blend_stdx.hpp"
 #include "blend_stdxa.hpp"
+#include "blend_af.hpp"
 #include "blend_wave.hpp"
 
 namespace {
@@ -108,7 +109,10 @@ void launch_wave(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 
 // STD through blend_planar<STDF> (MFMA sum + exact recomputation inside the rounding band) when launch_blend has validated the
 // planar copy and the weights for it, else the exact-fp32 MFMA kernels
-void launch_std_filtered(const lfi_ctx *c, const KernelArgs &a_in, bool all_focus)
+// GATHER_ONCE = false ("filtered_regather"): all-focus renders of three or four chunks of images by round 3's blend_stdxa, which gathers
+// chunks 2 and 3 a second time for the chain — kept as the A/B partner and second implementation of blend_afs
+template <bool GATHER_ONCE>
+void launch_std_filtered_t(const lfi_ctx *c, const KernelArgs &a_in, bool all_focus)
 {
     if(all_focus && c->weights_scalable && c->weights_sum_ok && !a_in.prequant && a_in.k_pad <= 4 * 64)
     {
@@ -117,6 +121,26 @@ void launch_std_filtered(const lfi_ctx *c, const KernelArgs &a_in, bool all_focu
         const int n_tiles = tiles_x * a_in.out_rows;
         const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
         const int nch = (a_in.k_pad + 63) / 64;
+        if(nch >= 3 && GATHER_ONCE)
+        {
+            // three or four chunks of images: blend_afs — 64-pixel tiles whose whole stack of samples stays in LDS, every sample gathered
+            // once (blend_stdxa gathers chunks 2 and 3 a second time for the chain)
+            const int tiles_x64 = (a_in.width + lfi::AF_TPX - 1) / lfi::AF_TPX;
+            const int n_tiles64 = tiles_x64 * a_in.out_rows;
+            const dim3 grid64(std::min(n_tiles64, 2 * cu_count_of(c)));
+            note_kernel(c, "blend_afs<STD,allfocus>");
+            for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 64)
+            {
+                KernelArgs a = a_in;
+                a.v0 = v0;
+                a.v1 = std::min(v0 + 64, a_in.v1);
+                if(nch == 3)
+                    hipLaunchKernelGGL((lfi::blend_afs<true, 3>), grid64, block, 0, stream_of(c), a, tiles_x64, n_tiles64);
+                else
+                    hipLaunchKernelGGL((lfi::blend_afs<true, 4>), grid64, block, 0, stream_of(c), a, tiles_x64, n_tiles64);
+            }
+            return;
+        }
         note_kernel(c, "blend_stdxa<STD,allfocus>");
         for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 64)
         {
@@ -215,7 +239,8 @@ const Variant kTenVariants[] = {
     {"direct_p1m2", launch_ten_direct<1, 2>, false, true}, // generic: any weights, pre-quantisation dump, per-batch rounding
 };
 const Variant kStdVariants[] = {
-    {"filtered_m2_nt", launch_std_filtered, false, false, true, true}, // blend_wave / blend_persist where it does not apply
+    {"filtered_m2_nt", launch_std_filtered_t<true>, false, false, true, true}, // blend_wave / blend_persist where it does not apply
+    {"filtered_regather", launch_std_filtered_t<false>, false, false, true, true}, // the same with round 3's all-focus kernel (blend_stdxa) for 3–4 chunks
     {"wave_m2_nt", launch_wave<true, 2, true>, false, false, true},    // blend_persist where blend_wave does not apply
     {"persist_m2_nt", launch_persist<true, 2, true>, false, false, true},
     {"mfma_p1m2", launch_std_mfma<1, 2>, false, true}, // generic: pre-quantisation dump
