@@ -37,6 +37,12 @@
 
 namespace lfi {
 
+// measurement builds only (hipcc -DLFI_AF_ABL=mask, tools/af_ablate.sh): 1 = no chain arithmetic, 2 = no MFMA k-loops, 4 = no gathers,
+// 8 = no band test / stores / queue.  Outputs are wrong by construction.
+#ifndef LFI_AF_ABL
+#define LFI_AF_ABL 0
+#endif
+
 constexpr int AF_TPX = 64;                   // pixels per tile (one row)
 constexpr int AF_KC = 64;                    // images per chunk
 constexpr int AF_SLOT_DW = AF_KC * AF_TPX;   // dwords per slot (16 KB)
@@ -90,65 +96,106 @@ __device__ __forceinline__ float af_map_focus(const uint32_t m, const float focu
     return __builtin_fmaf(__fdiv_rn(static_cast<float>(m & 0xffu), 255.0f), range, focus);
 }
 
-// The per-pixel gather of one chunk of a tile into a slot: per image one 4-byte LDS-DMA per lane at (int)fma(f, offset, coord), clamped
-// (src/kernels.cu:78-82, :125); wave w moves images w, w + 4, ….  Returns the wave's DMA instructions (wave-uniform).
+// The per-pixel gather of one chunk of a tile into a slot (src/kernels.cu:78-82, :125): every lane warps ITS pixel of the tile,
+// (sx, sy) = clamp((int)fma(f, offset, coord)), for the four images of a quad; wave w moves the quads w, w + 4, … of the chunk.
+//   * the shifts of all four images are the same for all 64 pixels (a tile inside one region of the focus map, away from the image
+//     borders — half the tiles of a real map, all of a constant one): the four 256-byte runs travel in ONE 16-byte-per-lane LDS-DMA
+//     (lane l: image l >> 4, pixels 4(l & 15) … + 3) — a quarter of the instructions, whole sectors;
+//   * otherwise one 4-byte LDS-DMA per lane and image, at the lane's own address.
+// Either way the slot holds [image][64 pixels] dwords.  ox_tab / oy_tab: the chunk's float offsets, image 64·chunk + l in lane l
+// (registers filled once per launch: a v_readlane per image instead of a scalar load and its wait).  Returns the wave's DMA instructions
+// (wave-uniform).
 __device__ __forceinline__ int af_gather(const KernelArgs &a, const uint32_t *grid32, const size_t plane_px, const uint32_t slot_addr, const int chunk, const int x0,
-                                         const int y_img, const float f, const int wave, const int lane)
+                                         const int y_img, const float f, const int wave, const int lane, const float ox_tab, const float oy_tab)
 {
-    typedef const __attribute__((address_space(4))) float *const_float_ptr;
-    const const_float_ptr c_offsets = (const_float_ptr)(uintptr_t)a.offsets;
     const int W = a.width, H = a.height;
     const int k0 = AF_KC * chunk;
     const int kn = min(AF_KC, a.n_images - k0);
     const float xf = static_cast<float>(x0 + lane), yf = static_cast<float>(y_img);
+    const bool runs_ok = plane_px < (size_t(1) << 28); // four planes within a 32-bit byte offset
+    const uint32_t plane_b = uint32_t(plane_px) * 4u;
     int count = 0;
-    int gi = wave;
-    float ox = 0.0f, oy = 0.0f;
-    if(gi < kn)
+    for(int q = wave; 4 * q < kn; q += 4)
     {
-        ox = c_offsets[2 * (k0 + gi)];
-        oy = c_offsets[2 * (k0 + gi) + 1];
-    }
-    for(; gi < kn; gi += 4)
-    {
-        const int gn = min(gi + 4, kn - 1);
-        const float ox_n = c_offsets[2 * (k0 + gn)], oy_n = c_offsets[2 * (k0 + gn) + 1]; // for the next iteration
-        const int sx = clampi(static_cast<int>(__builtin_fmaf(f, ox, xf)), 0, W - 1); // min(max()) → v_med3_i32
-        const int sy = clampi(static_cast<int>(__builtin_fmaf(f, oy, yf)), 0, H - 1);
         // rows are indexed inside the held window: −in_y0·W folded into the scalar base (W, H < 2^24: lfi_set_grid)
-        const uint32_t *base = grid32 + (size_t)(k0 + gi) * plane_px - (size_t)a.in_y0 * W;
-        dma4_s(base, (__umul24(uint32_t(sy), uint32_t(W)) + uint32_t(sx)) << 2, slot_addr + uint32_t(gi) * (AF_TPX * 4u));
-        count++;
-        ox = ox_n;
-        oy = oy_n;
+        const uint32_t *base = grid32 + (size_t)(k0 + 4 * q) * plane_px - (size_t)a.in_y0 * W;
+        int sx[4], sy[4], sx0[4], sy0[4];
+        bool same = true;
+#pragma unroll
+        for(int i = 0; i < 4; i++)
+        {
+            const int gi = min(4 * q + i, kn - 1); // past the chunk's last image: that image again (zero weights)
+            const float ox = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ox_tab), gi));
+            const float oy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oy_tab), gi));
+            sx[i] = clampi(static_cast<int>(__builtin_fmaf(f, ox, xf)), 0, W - 1); // min(max()) → v_med3_i32
+            sy[i] = clampi(static_cast<int>(__builtin_fmaf(f, oy, yf)), 0, H - 1);
+            sx0[i] = __builtin_amdgcn_readfirstlane(sx[i]);
+            sy0[i] = __builtin_amdgcn_readfirstlane(sy[i]);
+            same = same && (sx[i] - lane == sx0[i]) && (sy[i] == sy0[i]);
+        }
+        if constexpr(!(LFI_AF_ABL & 4))
+        {
+            if(runs_ok && __builtin_amdgcn_ballot_w64(same) == ~0ull)
+            {
+                uint32_t off[4];
+#pragma unroll
+                for(int i = 0; i < 4; i++)
+                    off[i] = uint32_t(min(4 * q + i, kn - 1) - 4 * q) * plane_b + ((__umul24(uint32_t(sy0[i]), uint32_t(W)) + uint32_t(sx0[i])) << 2);
+                const int img = lane >> 4;
+                const uint32_t voff = (img == 0 ? off[0] : (img == 1 ? off[1] : (img == 2 ? off[2] : off[3]))) + 16u * uint32_t(lane & 15);
+                dma16_s(base, voff, slot_addr + uint32_t(4 * q) * (AF_TPX * 4u));
+                count++;
+            }
+            else
+            {
+#pragma unroll
+                for(int i = 0; i < 4; i++)
+                    if(4 * q + i < kn) // wave-uniform
+                    {
+                        dma4_s(base + (size_t)i * plane_px, (__umul24(uint32_t(sy[i]), uint32_t(W)) + uint32_t(sx[i])) << 2, slot_addr + uint32_t(4 * q + i) * (AF_TPX * 4u));
+                        count++;
+                    }
+            }
+        }
     }
     return count;
 }
 
-// fp16 MFMA k-loop of one chunk from a slot: this wave's 32 pixels × 32 views, weights from the A fragments in registers
+// fp16 MFMA k-loop of one chunk from a slot: this wave's 32 pixels × 32 views, weights from the A fragments in registers.  The LDS reads of
+// k-step ks + 1 are issued before the MFMAs of k-step ks (register double buffer + a scheduling barrier): written as read → permute → MFMA
+// per k-step, every k-step began with an exposed LDS latency (0.84 ms of k-loops at config 5, tools/af_ablate.sh).
 template <bool ZERO_FIRST>
 __device__ __forceinline__ void af_mfma_unit(const uint32_t *col, const half8 *wk, const int kc, f32x16 (&acc)[3])
 {
+    constexpr int KS = AF_KC / 16;
     f32x16 zero16;
 #pragma unroll
     for(int e = 0; e < 16; e++)
         zero16[e] = 0.0f;
+    uint32_t px[2][8];
 #pragma unroll
-    for(int ks = 0; ks < AF_KC / 16; ks++)
+    for(int j = 0; j < 8; j++)
+        px[0][j] = col[j * AF_TPX];
+#pragma unroll
+    for(int ks = 0; ks < KS; ks++)
     {
         if(16 * ks < kc) // wave-uniform: a chunk's length is a multiple of 16
         {
-            uint32_t px[8];
+            if(ks + 1 < KS && 16 * (ks + 1) < kc)
+            {
 #pragma unroll
-            for(int j = 0; j < 8; j++)
-                px[j] = col[(16 * ks + j) * AF_TPX];
+                for(int j = 0; j < 8; j++)
+                    px[(ks + 1) & 1][j] = col[(16 * (ks + 1) + j) * AF_TPX];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t(&p)[8] = px[ks & 1];
             u32x4 bc[3];
 #pragma unroll
             for(int q = 0; q < 4; q++)
             {
-                bc[0][q] = pack_subnormal_pair<0>(px[2 * q], px[2 * q + 1]);
-                bc[1][q] = pack_subnormal_pair<1>(px[2 * q], px[2 * q + 1]);
-                bc[2][q] = pack_subnormal_pair<2>(px[2 * q], px[2 * q + 1]);
+                bc[0][q] = pack_subnormal_pair<0>(p[2 * q], p[2 * q + 1]);
+                bc[1][q] = pack_subnormal_pair<1>(p[2 * q], p[2 * q + 1]);
+                bc[2][q] = pack_subnormal_pair<2>(p[2 * q], p[2 * q + 1]);
             }
 #pragma unroll
             for(int c = 0; c < 3; c++)
@@ -199,6 +246,19 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
     for(int s = 0; s < KS * NCH; s++)
         asm volatile("" : "+v"(wreg[s]));
 
+    // the float offsets of all images, chunk c's image 64c + l in lane l of ox_tab[c] / oy_tab[c]: the gathers read them with v_readlane
+    float ox_tab[NCH], oy_tab[NCH];
+#pragma unroll
+    for(int c = 0; c < NCH; c++)
+    {
+        const lfi_float2 o = a.offsets[min(AF_KC * c + lane, a.n_images - 1)];
+        ox_tab[c] = o.x;
+        oy_tab[c] = o.y;
+    }
+#pragma unroll
+    for(int c = 0; c < NCH; c++)
+        asm volatile("" : "+v"(ox_tab[c]), "+v"(oy_tab[c]));
+
     const int G = gridDim.x;
     const int t0 = int(xcd_contiguous(blockIdx.x, gridDim.x));
     if(t0 >= n_tiles)
@@ -230,28 +290,34 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
         const uint32_t px = entry & 31u, view = (entry >> 5) & 31u, ch = (entry >> 11) & 3u;
         const uint8_t *pb = reinterpret_cast<const uint8_t *>(lds + slot * AF_SLOT_DW) + (32 * ph + px) * 4 + ch;
         float s = s15;
-#pragma unroll
-        for(int ks = 0; ks < KS; ks++)
-        {
-            if(16 * ks >= kc) // wave-uniform
-                break;
-            uint32_t w2[8], pbyte[16];
+        uint32_t w2[2][8], pbyte[2][16];
+        // the LDS traffic of k-step ks + 1 — 8 weight pairs across lanes, 16 pixel bytes — is issued before the 16 dependent fmas of k-step ks
+        auto stage = [&](const int ks, uint32_t (&w)[8], uint32_t (&p)[16]) {
             const u32x4 wv = __builtin_bit_cast(u32x4, wreg[KS * cc + ks]);
 #pragma unroll
             for(int hh = 0; hh < 2; hh++)
 #pragma unroll
                 for(int d = 0; d < 4; d++)
-                    w2[4 * hh + d] = uint32_t(__builtin_amdgcn_ds_bpermute(4 * (int(view) + 32 * hh), int(wv[d])));
+                    w[4 * hh + d] = uint32_t(__builtin_amdgcn_ds_bpermute(4 * (int(view) + 32 * hh), int(wv[d])));
 #pragma unroll
             for(int j = 0; j < 16; j++)
-                pbyte[j] = pb[(16 * ks + j) * AF_TPX * 4];
+                p[j] = pb[(16 * ks + j) * AF_TPX * 4];
+        };
+        stage(0, w2[0], pbyte[0]);
+#pragma unroll
+        for(int ks = 0; ks < KS; ks++)
+        {
+            if(16 * ks >= kc) // wave-uniform
+                break;
+            if(ks + 1 < KS && 16 * (ks + 1) < kc)
+                stage(ks + 1, w2[(ks + 1) & 1], pbyte[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for(int j = 0; j < 16; j++) // image 64·cc + 16·ks + j, ascending
             {
-                const uint32_t pair = w2[j >> 1];
+                const uint32_t pair = w2[ks & 1][j >> 1];
                 const float w = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(j & 1 ? pair >> 16 : pair)));
-                s = __builtin_fmaf(static_cast<float>(pbyte[j]), w, s); // addWeighted, src/kernels.cu:292-299
+                s = __builtin_fmaf(static_cast<float>(pbyte[ks & 1][j]), w, s); // addWeighted, src/kernels.cu:292-299
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -271,7 +337,7 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
 #pragma unroll
         for(int c = 1; c < NCH; c++)
         {
-            issued += af_gather(a, grid32, plane_px, lds_base + uint32_t(wrap(slot_base + fetch_order(c))) * (AF_SLOT_DW * 4u), c, x0, a.out_y0 + ty, f_issue, wave, lane);
+            issued += af_gather(a, grid32, plane_px, lds_base + uint32_t(wrap(slot_base + fetch_order(c))) * (AF_SLOT_DW * 4u), c, x0, a.out_y0 + ty, f_issue, wave, lane, ox_tab[c], oy_tab[c]);
             mark_cur[c] = issued;
         }
     }
@@ -310,7 +376,7 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
         if constexpr(u == 0)
         {
             // c0 of THIS tile into the slot of the previous tile's c(NCH−1), whose last link of the chain has run
-            issued += af_gather(a, grid32, plane_px, lds_base + uint32_t(wrap(slot_base + fetch_order(0))) * (AF_SLOT_DW * 4u), 0, x0, a.out_y0 + ty, f_issue, wave, lane);
+            issued += af_gather(a, grid32, plane_px, lds_base + uint32_t(wrap(slot_base + fetch_order(0))) * (AF_SLOT_DW * 4u), 0, x0, a.out_y0 + ty, f_issue, wave, lane, ox_tab[0], oy_tab[0]);
             mark_cur[0] = issued;
         }
         const int slot_base_next = slot_base == 0 ? NS - 1 : slot_base - 1;
@@ -320,7 +386,7 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
             {
                 f_issue = af_map_focus(m_next, a.focus, a.range);
                 // c1 of the NEXT tile into the spare slot
-                issued += af_gather(a, grid32, plane_px, lds_base + uint32_t(wrap(slot_base_next + fetch_order(1))) * (AF_SLOT_DW * 4u), 1, x0n, a.out_y0 + tyn, f_issue, wave, lane);
+                issued += af_gather(a, grid32, plane_px, lds_base + uint32_t(wrap(slot_base_next + fetch_order(1))) * (AF_SLOT_DW * 4u), 1, x0n, a.out_y0 + tyn, f_issue, wave, lane, ox_tab[1], oy_tab[1]);
                 mark_next[1] = issued;
             }
         }
@@ -330,7 +396,7 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
             constexpr int k = u - NCH + 1;
             if(has_next)
             {
-                issued += af_gather(a, grid32, plane_px, lds_base + uint32_t(wrap(slot_base_next + fetch_order(k))) * (AF_SLOT_DW * 4u), k, x0n, a.out_y0 + tyn, f_issue, wave, lane);
+                issued += af_gather(a, grid32, plane_px, lds_base + uint32_t(wrap(slot_base_next + fetch_order(k))) * (AF_SLOT_DW * 4u), k, x0n, a.out_y0 + tyn, f_issue, wave, lane, ox_tab[k], oy_tab[k]);
                 mark_next[k] = issued;
             }
         }
@@ -338,7 +404,7 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
         const int kc = min(AF_KC, a.k_pad - AF_KC * cc);
         const int slot = wrap(slot_base + fetch_order(cc));
         const int xw = x0 + 32 * ph;
-        if constexpr(is_m)
+        if constexpr(is_m && !(LFI_AF_ABL & 2))
         {
             const uint32_t *col = lds + slot * AF_SLOT_DW + 32 * ph + r + 8 * h * AF_TPX;
             if constexpr(u == 0)
@@ -346,7 +412,7 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
             else
                 af_mfma_unit<false>(col, &wreg[KS * cc], kc, acc);
         }
-        if constexpr(is_mc)
+        if constexpr(is_mc && !(LFI_AF_ABL & 8))
         {
             // ---- epilogue: round every sum, store RGBA, find the sums inside the band (accumulator e ↔ view (e&3) + 8(e>>2) + 4h of the wave)
             uint32_t flagged[3] = {0u, 0u, 0u}; // per channel: bit e
@@ -456,7 +522,7 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
             queued = min(count, QCAP);
             s0 = s1 = 0.0f;
         }
-        if constexpr(u >= NCH - 1)
+        if constexpr(u >= NCH - 1 && !(LFI_AF_ABL & 1))
         {
             // the chain over chunk cc for the queued sums, from the slot the chunk landed in
             if(queued > 0)

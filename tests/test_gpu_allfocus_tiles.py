@@ -100,10 +100,11 @@ def test_structured_maps_match_the_oracle(case, gpu, oracle_c):
         ctx.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_structured_map_row_bands(world, gpu, oracle_c):
-    """Row-band sharding of an all-focus render from a structured map: every band gives its rows of the full render."""
-    cols = rows = 8
+@pytest.mark.parametrize("world,cols", [(2, 8), (3, 8), (2, 13)])
+def test_structured_map_row_bands(world, cols, gpu, oracle_c):
+    """Row-band sharding of an all-focus render from a structured map: every band gives its rows of the full render.  (13×13: three chunks
+    of images — the kernels of blend_af.hpp, whose tiles are 64 pixels.)"""
+    rows = cols
     W, H, V = 260, 48, 6
     hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.04, 0.2, 3.0, 1.783, V)
     lf = oracle_c.synthetic_lf(cols * rows, W, H, SEED)
