@@ -96,15 +96,11 @@ __device__ __forceinline__ float af_map_focus(const uint32_t m, const float focu
     return __builtin_fmaf(__fdiv_rn(static_cast<float>(m & 0xffu), 255.0f), range, focus);
 }
 
-// The per-pixel gather of one chunk of a tile into a slot (src/kernels.cu:78-82, :125): every lane warps ITS pixel of the tile,
-// (sx, sy) = clamp((int)fma(f, offset, coord)), for the four images of a quad; wave w moves the quads w, w + 4, … of the chunk.
-//   * the shifts of all four images are the same for all 64 pixels (a tile inside one region of the focus map, away from the image
-//     borders — half the tiles of a real map, all of a constant one): the four 256-byte runs travel in ONE 16-byte-per-lane LDS-DMA
-//     (lane l: image l >> 4, pixels 4(l & 15) … + 3) — a quarter of the instructions, whole sectors;
-//   * otherwise one 4-byte LDS-DMA per lane and image, at the lane's own address.
-// Either way the slot holds [image][64 pixels] dwords.  ox_tab / oy_tab: the chunk's float offsets, image 64·chunk + l in lane l
+// The per-pixel gather of one chunk of a tile into a slot: per image one 4-byte LDS-DMA per lane at (int)fma(f, offset, coord), clamped
+// (src/kernels.cu:78-82, :125); wave w moves images w, w + 4, ….  ox_tab / oy_tab: the chunk's float offsets, image 64·chunk + l in lane l
 // (registers filled once per launch: a v_readlane per image instead of a scalar load and its wait).  Returns the wave's DMA instructions
-// (wave-uniform).
+// (wave-uniform).  (Measured and removed, profiles/r04_notes.md: one 16-byte-per-lane DMA for four images whose shifts are uniform over
+// the tile — the test costs more vector instructions than the three DMA instructions it saves; the kernel is bound by instruction issue.)
 __device__ __forceinline__ int af_gather(const KernelArgs &a, const uint32_t *grid32, const size_t plane_px, const uint32_t slot_addr, const int chunk, const int x0,
                                          const int y_img, const float f, const int wave, const int lane, const float ox_tab, const float oy_tab)
 {
@@ -112,51 +108,21 @@ __device__ __forceinline__ int af_gather(const KernelArgs &a, const uint32_t *gr
     const int k0 = AF_KC * chunk;
     const int kn = min(AF_KC, a.n_images - k0);
     const float xf = static_cast<float>(x0 + lane), yf = static_cast<float>(y_img);
-    const bool runs_ok = plane_px < (size_t(1) << 28); // four planes within a 32-bit byte offset
-    const uint32_t plane_b = uint32_t(plane_px) * 4u;
     int count = 0;
-    for(int q = wave; 4 * q < kn; q += 4)
+    // rows are indexed inside the held window: −in_y0·W folded into the scalar base (W, H < 2^24: lfi_set_grid)
+    const uint32_t *base = grid32 + (size_t)(k0 + wave) * plane_px - (size_t)a.in_y0 * W;
+    for(int gi = wave; gi < kn; gi += 4)
     {
-        // rows are indexed inside the held window: −in_y0·W folded into the scalar base (W, H < 2^24: lfi_set_grid)
-        const uint32_t *base = grid32 + (size_t)(k0 + 4 * q) * plane_px - (size_t)a.in_y0 * W;
-        int sx[4], sy[4], sx0[4], sy0[4];
-        bool same = true;
-#pragma unroll
-        for(int i = 0; i < 4; i++)
-        {
-            const int gi = min(4 * q + i, kn - 1); // past the chunk's last image: that image again (zero weights)
-            const float ox = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ox_tab), gi));
-            const float oy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oy_tab), gi));
-            sx[i] = clampi(static_cast<int>(__builtin_fmaf(f, ox, xf)), 0, W - 1); // min(max()) → v_med3_i32
-            sy[i] = clampi(static_cast<int>(__builtin_fmaf(f, oy, yf)), 0, H - 1);
-            sx0[i] = __builtin_amdgcn_readfirstlane(sx[i]);
-            sy0[i] = __builtin_amdgcn_readfirstlane(sy[i]);
-            same = same && (sx[i] - lane == sx0[i]) && (sy[i] == sy0[i]);
-        }
+        const float ox = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ox_tab), gi));
+        const float oy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oy_tab), gi));
+        const int sx = clampi(static_cast<int>(__builtin_fmaf(f, ox, xf)), 0, W - 1); // min(max()) → v_med3_i32
+        const int sy = clampi(static_cast<int>(__builtin_fmaf(f, oy, yf)), 0, H - 1);
         if constexpr(!(LFI_AF_ABL & 4))
         {
-            if(runs_ok && __builtin_amdgcn_ballot_w64(same) == ~0ull)
-            {
-                uint32_t off[4];
-#pragma unroll
-                for(int i = 0; i < 4; i++)
-                    off[i] = uint32_t(min(4 * q + i, kn - 1) - 4 * q) * plane_b + ((__umul24(uint32_t(sy0[i]), uint32_t(W)) + uint32_t(sx0[i])) << 2);
-                const int img = lane >> 4;
-                const uint32_t voff = (img == 0 ? off[0] : (img == 1 ? off[1] : (img == 2 ? off[2] : off[3]))) + 16u * uint32_t(lane & 15);
-                dma16_s(base, voff, slot_addr + uint32_t(4 * q) * (AF_TPX * 4u));
-                count++;
-            }
-            else
-            {
-#pragma unroll
-                for(int i = 0; i < 4; i++)
-                    if(4 * q + i < kn) // wave-uniform
-                    {
-                        dma4_s(base + (size_t)i * plane_px, (__umul24(uint32_t(sy[i]), uint32_t(W)) + uint32_t(sx[i])) << 2, slot_addr + uint32_t(4 * q + i) * (AF_TPX * 4u));
-                        count++;
-                    }
-            }
+            dma4_s(base, (__umul24(uint32_t(sy), uint32_t(W)) + uint32_t(sx)) << 2, slot_addr + uint32_t(gi) * (AF_TPX * 4u));
+            count++;
         }
+        base += 4 * plane_px;
     }
     return count;
 }

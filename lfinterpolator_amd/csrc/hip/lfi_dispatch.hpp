@@ -109,8 +109,10 @@ void launch_wave(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 
 // STD through blend_planar<STDF> (MFMA sum + exact recomputation inside the rounding band) when launch_blend has validated the
 // planar copy and the weights for it, else the exact-fp32 MFMA kernels
-// GATHER_ONCE = false ("filtered_regather"): all-focus renders of three or four chunks of images by round 3's blend_stdxa, which gathers
-// chunks 2 and 3 a second time for the chain — kept as the A/B partner and second implementation of blend_afs
+// GATHER_ONCE = true ("filtered_gather_once"): all-focus renders of three or four chunks of images by blend_afs (round 4: 64-pixel tiles whose
+// whole stack of samples stays in LDS, every sample gathered once) instead of blend_stdxa, which gathers chunks 2 and 3 a second time for
+// the chain.  Half the fabric traffic, the same bytes — and not faster (4.8 against 4.7 ms at config 5: bound by instruction issue, see
+// profiles/r04_notes.md), so it is a selectable variant and the second implementation in the parity tests, not the default.
 template <bool GATHER_ONCE>
 void launch_std_filtered_t(const lfi_ctx *c, const KernelArgs &a_in, bool all_focus)
 {
@@ -239,8 +241,8 @@ const Variant kTenVariants[] = {
     {"direct_p1m2", launch_ten_direct<1, 2>, false, true}, // generic: any weights, pre-quantisation dump, per-batch rounding
 };
 const Variant kStdVariants[] = {
-    {"filtered_m2_nt", launch_std_filtered_t<true>, false, false, true, true}, // blend_wave / blend_persist where it does not apply
-    {"filtered_regather", launch_std_filtered_t<false>, false, false, true, true}, // the same with round 3's all-focus kernel (blend_stdxa) for 3–4 chunks
+    {"filtered_m2_nt", launch_std_filtered_t<false>, false, false, true, true}, // blend_wave / blend_persist where it does not apply
+    {"filtered_gather_once", launch_std_filtered_t<true>, false, false, true, true}, // the same with blend_afs for all-focus renders of 3–4 chunks
     {"wave_m2_nt", launch_wave<true, 2, true>, false, false, true},    // blend_persist where blend_wave does not apply
     {"persist_m2_nt", launch_persist<true, 2, true>, false, false, true},
     {"mfma_p1m2", launch_std_mfma<1, 2>, false, true}, // generic: pre-quantisation dump

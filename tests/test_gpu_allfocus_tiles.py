@@ -86,6 +86,12 @@ def test_structured_maps_match_the_oracle(case, gpu, oracle_c):
         ten = ctx.download_views()
         assert (std == want_std).all(), (flags, int((std != want_std).sum()))
         assert np.abs(ten.astype(int) - want_ten.astype(int)).max() <= TEN_TOL_LSB, flags
+        if cols * rows > 128:                      # three or four chunks of images: blend_afs (every sample gathered once) gives the same bytes
+            ctx.set_variant("STD", "filtered_gather_once")
+            ctx.render("STD", all_focus=True)
+            ctx.sync()
+            assert ctx.last_kernel_name() == "blend_afs<STD,allfocus>" and (ctx.download_views() == want_std).all(), flags
+            ctx.set_variant("STD", "auto")
         # a view range, and the planar view layout (RGBA kernel + conversion)
         ctx.render("TEN_WM", all_focus=True, v0=V // 2, v1=V // 2 + 1)
         ctx.sync()
@@ -103,7 +109,7 @@ def test_structured_maps_match_the_oracle(case, gpu, oracle_c):
 @pytest.mark.parametrize("world,cols", [(2, 8), (3, 8), (2, 13)])
 def test_structured_map_row_bands(world, cols, gpu, oracle_c):
     """Row-band sharding of an all-focus render from a structured map: every band gives its rows of the full render.  (13×13: three chunks
-    of images — the kernels of blend_af.hpp, whose tiles are 64 pixels.)"""
+    of images — the bands' STD renders go through blend_afs, whose tiles are 64 pixels.)"""
     rows = cols
     W, H, V = 260, 48, 6
     hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.04, 0.2, 3.0, 1.783, V)
@@ -134,6 +140,8 @@ def test_structured_map_row_bands(world, cols, gpu, oracle_c):
             ctx.set_params(hp)
             for k in (0, 1):
                 ctx.upload_map(k, m)
+            if cols * rows > 128:
+                ctx.set_variant("STD", "filtered_gather_once")
             ctx.render(method, all_focus=True)
             ctx.sync()
             got |= ctx.download_views()

@@ -652,9 +652,9 @@ def test_std_band_method_over_several_chunks(cols, rows, W, H, V, kind, gpu, ora
 ])
 def test_all_focus_std_band_method(cols, rows, W, H, V, kind, gpu, oracle_c):
     """All-focus STD by the band method: fp16-MFMA sums of the per-pixel gathered samples over all chunks, the sums inside the rounding band
-    recomputed with the chain.  One or two chunks of images: blend_stdxa (128-pixel tiles; everything the chain needs is still in LDS).  Three
-    or four chunks: blend_afs (round 4: 64-pixel tiles whose whole stack stays in LDS, every sample gathered once); round 3's blend_stdxa,
-    which gathers chunks 2 and 3 a second time, stays selectable ("filtered_regather") and must give the same bytes.  Bit-exact against the
+    recomputed with the chain: blend_stdxa (128-pixel tiles; chunks 2 and 3 of a tile are gathered a second time for the chain).  For three
+    or four chunks blend_afs (round 4: 64-pixel tiles whose whole stack stays in LDS, every sample gathered once; variant
+    "filtered_gather_once") must give the same bytes.  Bit-exact against the
     oracle on random inputs and on inputs built to sit on the band, with noisy and blocky focus maps, the analytic band, a view range, a row
     band and the planar view layout."""
     n = cols * rows
@@ -687,14 +687,14 @@ def test_all_focus_std_band_method(cols, rows, W, H, V, kind, gpu, oracle_c):
         ctx.upload_map(1, m)                   # Standard::process<true> reads map 1 (src/kernels.cu:326)
         ctx.render("STD", all_focus=True)
         ctx.sync()
-        assert ctx.last_kernel_name() == ("blend_afs<STD,allfocus>" if n > 128 else "blend_stdxa<STD,allfocus>")
+        assert ctx.last_kernel_name() == "blend_stdxa<STD,allfocus>"
         got = ctx.download_views()
         assert (got == want).all(), (kind, flags, int((got != want).sum()))
         if n > 128:
-            ctx.set_variant("STD", "filtered_regather")
+            ctx.set_variant("STD", "filtered_gather_once")
             ctx.render("STD", all_focus=True)
             ctx.sync()
-            assert ctx.last_kernel_name() == "blend_stdxa<STD,allfocus>" and (ctx.download_views() == want).all(), (kind, flags, "round 3 kernel")
+            assert ctx.last_kernel_name() == "blend_afs<STD,allfocus>" and (ctx.download_views() == want).all(), (kind, flags, "blend_afs")
             ctx.set_variant("STD", "auto")
         if flags == 0:
             v0, v1 = V // 3, V // 3 + min(20, V - V // 3)

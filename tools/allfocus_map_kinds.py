@@ -1,5 +1,5 @@
 """Config 5 on the structured scene: all-focus renders from the estimated map and from a constant map, TEN_WM and STD (round 4: STD by
-blend_afs — every sample gathered once — and by round 3's blend_stdxa, variant "filtered_regather").  usage: python tools/allfocus_map_kinds.py"""
+blend_stdxa and by blend_afs — every sample gathered once, variant "filtered_gather_once").  usage: python tools/allfocus_map_kinds.py"""
 import sys
 sys.path.insert(0, ".")
 import numpy as np
@@ -20,10 +20,10 @@ def t(method, n=6):
 def line(tag):
     ten = t("TEN_WM"); k_ten = ctx.last_kernel_name()
     std = t("STD"); k_std = ctx.last_kernel_name()
-    ctx.set_variant("STD", "filtered_regather")
+    ctx.set_variant("STD", "filtered_gather_once")
     std_old = t("STD"); k_old = ctx.last_kernel_name()
     ctx.set_variant("STD", "auto")
-    print(f"{tag}: TEN {ten:.3f} ms ({k_ten})  STD {std:.3f} ms ({k_std})  STD round 3 {std_old:.3f} ms ({k_old})", flush=True)
+    print(f"{tag}: TEN {ten:.3f} ms ({k_ten})  STD {std:.3f} ms ({k_std})  STD gathered once {std_old:.3f} ms ({k_old})", flush=True)
 ctx.focus_map(); ctx.sync()
 line("estimated map")
 m = np.full((H, W, 4), 128, np.uint8); m[..., 3] = 255
