@@ -66,9 +66,13 @@ enum {
     /* STD through the band method (fp16 matrix-core sum, exact fmaf chain only for sums near x.5): size the band with the ANALYTIC
      * bound on the matrix core's accumulation error (one whole fp16-product ulp per addend, true of any accumulator that keeps ≥ 24
      * bits even if every addition truncated) instead of the bound measured on gfx950 (a quarter ulp per addend; asserted by
-     * tests/test_gpu_parity.py::test_mfma_f16_accumulation_error_bound).  Same bytes, ≈ 1.5× as many sums recomputed.  For callers
-     * who do not want bit-exactness to rest on a measured property of the hardware. */
-    LFI_FLAG_STD_ANALYTIC_BAND = 8u
+     * tests/test_gpu_parity.py::test_mfma_f16_accumulation_error_bound over 800 adversarial operand sets).  Same bytes, more sums
+     * recomputed.  Light fields of up to 64 images use the analytic band BY DEFAULT since round 4 (it costs nothing there); with more
+     * images (15x15 grids) it doubles the launch time (tools/std_band_cost.py), so there it stays opt-in, for callers who do not want
+     * bit-exactness to rest on a measured property of the hardware. */
+    LFI_FLAG_STD_ANALYTIC_BAND = 8u,
+    /* Up to 64 images: the band of the measured bound (rounds 2-3's default) instead of the analytic one.  Same bytes. */
+    LFI_FLAG_STD_MEASURED_BAND = 16u
 };
 
 #define LFI_MAX_IMAGES 256     /* MAX_IMAGES, src/kernels.cu:60 */

@@ -15,6 +15,7 @@ LFI_FLAG_UNIFIED_FOCUS_MAP = 1
 LFI_FLAG_TEN_ROUND_PER_BATCH = 2
 LFI_FLAG_SINGLE_SWEEP_DIRECTION = 4
 LFI_FLAG_STD_ANALYTIC_BAND = 8
+LFI_FLAG_STD_MEASURED_BAND = 16
 LFI_KERNEL_FOCUS_ESTIMATE = 2
 METHODS = {"STD": LFI_METHOD_STD, "TEN_WM": LFI_METHOD_TEN_WM, "FOCUS": LFI_KERNEL_FOCUS_ESTIMATE}
 

@@ -251,13 +251,15 @@ KernelArgs make_args(const lfi_ctx *c, int v0, int v1, int all_focus_method)
     a.n_focus_ids = c->n_focus_ids;
     a.planar = nullptr; // set by launch_blend when the copy is valid for this launch
     a.planar_phase = c->d_planar_phase;
-    // blend_planar<STDF>: chain bound N·2^-16 (half an ulp below 512 per fmaf: arithmetic) + MFMA accumulation bound N·2^-17 (a
-    // quarter ulp per addend: MEASURED on gfx950 — chains of v_mfma_f32_32x32x16_f16 on operands built to expose alignment
-    // truncation stay within 0.086 ulp per addend, tests/test_gpu_parity.py::test_mfma_f16_accumulation_error_bound asserts the
-    // quarter ulp used here) + 2^-11 of margin
-    a.std_band = float(c->n) * (0x1p-16f + 0x1p-17f) + 0x1p-11f;
-    if(c->flags & LFI_FLAG_STD_ANALYTIC_BAND) // N·2^-15 for the accumulation: nothing measured (include/lfi.h)
-        a.std_band = float(c->n) * (0x1p-16f + 0x1p-15f) + 0x1p-11f;
+    // blend_planar<STDF> (up to 64 images): chain bound N·2^-16 (half an ulp below 512 per fmaf: arithmetic) + the matrix core's accumulation
+    // bound + 2^-11 of margin.  Accumulation bound: ANALYTIC by default since round 4, N·2^-15 (one whole fp16-product ulp per addend: true of
+    // any accumulator that keeps ≥ 24 bits, nothing measured) — at these sizes the wider band costs nothing (tools/std_band_cost.py: config 2
+    // 0.262 against 0.270 ms).  LFI_FLAG_STD_MEASURED_BAND: N·2^-17, a quarter ulp per addend, MEASURED on gfx950 (chains of
+    // v_mfma_f32_32x32x16_f16 on operands built to expose alignment truncation stay within 0.086 ulp per addend;
+    // tests/test_gpu_parity.py::test_mfma_f16_accumulation_error_bound asserts the quarter ulp) — rounds 2-3's default.
+    a.std_band = float(c->n) * (0x1p-16f + 0x1p-15f) + 0x1p-11f;
+    if((c->flags & LFI_FLAG_STD_MEASURED_BAND) && !(c->flags & LFI_FLAG_STD_ANALYTIC_BAND))
+        a.std_band = float(c->n) * (0x1p-16f + 0x1p-17f) + 0x1p-11f;
     a.planar_pitch = c->planar_pitch;
     a.planar_padx = c->planar_padx;
     a.views_pitch = view_pitch(c);
