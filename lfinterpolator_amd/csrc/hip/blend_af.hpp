@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
 
     // ---- band constants (blend_stdx.hpp) ------------------------------------------------------------------------------------------------
     const float nf = float(a.n_images);
-    const float c0 = nf * ((a.flags & LFI_FLAG_STD_ANALYTIC_BAND) ? 0x1p-15f : 0x1p-17f) + 0x1p-12f;
+    const float c0 = nf * std_accumulation_bound(a.flags) + 0x1p-12f;
     const float bmax_acc = (c0 + nf * 0x1p-16f) * 0x1p-9f;
     const float base_acc = (0.5f - c0) * 0x1p-9f;
     const float chain_acc = nf * 0x1p-24f;

@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
 
     // ---- band constants (file header) ------------------------------------------------------------------------------------------------
     const float nf = float(a.n_images);
-    const float c0 = nf * ((a.flags & LFI_FLAG_STD_ANALYTIC_BAND) ? 0x1p-15f : 0x1p-17f) + 0x1p-12f; // accumulation error + margin, in units of S
+    const float c0 = nf * std_accumulation_bound(a.flags) + 0x1p-12f; // accumulation error + margin, in units of S
     const float bmax_acc = (c0 + nf * 0x1p-16f) * 0x1p-9f;  // the widest band (sums below 512), in units of acc
     const float base_acc = (0.5f - c0) * 0x1p-9f;           // inside(acc) = base − N·2^-24·pow2(acc + bmax): |d| above it ⇒ recompute
     const float chain_acc = nf * 0x1p-24f;

@@ -63,6 +63,17 @@ struct KernelArgs
     uint32_t flags;
 };
 
+// The band method's bound on the matrix core's accumulation error per addend (in units of S, sums below 512) for MORE than 64 images
+// (blend_stdx, blend_stdxa, blend_afs): 2^-17, a quarter ulp(512), MEASURED on gfx950 — at most 0.21 ulp(512) = 0.83·2^-17 per addend over
+// 800 adversarial operand sets (tests/test_gpu_parity.py::test_mfma_f16_accumulation_error_bound asserts 2^-17; rounds 2-3 had probed 2
+// sets and seen 0.09 ulp) — plus the band's 2^-12 of margin.  LFI_FLAG_STD_ANALYTIC_BAND: 2^-15, true of any accumulator that keeps 24
+// bits — twice the launch time at 15x15; a budget of 2^-16 would cost 8-12 % (profiles/r04_std_band_cost.txt), so the asserted bound stays
+// the default here, while up to 64 images the analytic band is the default (lfi_context.hpp make_args: it is free there).
+__host__ __device__ __forceinline__ float std_accumulation_bound(const uint32_t flags)
+{
+    return (flags & LFI_FLAG_STD_ANALYTIC_BAND) ? 0x1p-15f : 0x1p-17f;
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi)
 {
     return min(max(v, lo), hi);
