@@ -254,6 +254,11 @@ int lfi_download_map(lfi_ctx *ctx, int k, uint8_t *rgba, size_t pitch_bytes);
  * scripts/viewsToQuilt.sh builds with ImageMagick `montage -tile 5x9` from the NN.png files (Looking-Glass quilt).
  * rgba: (tiles_y*H) rows of pitch_bytes ≥ tiles_x*W*4.  Synchronous. */
 int lfi_download_quilt(lfi_ctx *ctx, int tiles_x, int tiles_y, int v0, uint8_t *rgba, size_t pitch_bytes);
+/* The same for PART of a quilt: views v0 … v0+n-1 of this context become tiles first_tile … first_tile+n-1 (row-major) of the
+ * tiles_x × tiles_y quilt whose top-left pixel is at rgba — a trajectory sharded over several GPUs (src/interpolator.cu has one GPU;
+ * the CLI's -g): every context fills its own tiles of one host image.  The tiles are assembled on the device by one kernel (the
+ * planar view layout is expanded on the fly) and copied in at most three rectangles; lfi_download_quilt is this with every tile. */
+int lfi_download_quilt_tiles(lfi_ctx *ctx, int tiles_x, int tiles_y, int first_tile, int n, int v0, uint8_t *rgba, size_t pitch_bytes);
 int lfi_upload_map(lfi_ctx *ctx, int k, const uint8_t *rgba, size_t pitch_bytes); /* tests: inject a focus map */
 
 /* PSNR / SSIM of rendered view v against a reference image on the host, reduced on the device — replaces

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "lfi_create", "lfi_destroy", "lfi_last_error", "lfi_abi_version", "lfi_device_count", "lfi_set_grid", "lfi_set_row_window",
     "lfi_upload_image", "lfi_attach_grid", "lfi_broadcast_grid", "lfi_grid_device_ptr", "lfi_fill_synthetic", "lfi_set_params",
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
-    "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
+    "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_download_quilt_tiles", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
     "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_fill_synthetic_scene", "lfi_upload_image_async", "lfi_upload_wait", "lfi_render_stream", "lfi_compare_view", "lfi_debug_mfma_f16_chain", "lfi_debug_pk_minmax3_f16",
 ]
@@ -110,6 +110,7 @@ def load_hip_library() -> C.CDLL:
         "lfi_download_view": (i, [vp, i, vp, sz]),
         "lfi_download_map": (i, [vp, i, vp, sz]),
         "lfi_download_quilt": (i, [vp, i, i, i, vp, sz]),
+        "lfi_download_quilt_tiles": (i, [vp, i, i, i, i, i, vp, sz]),
         "lfi_alloc_pinned": (i, [sz, C.POINTER(vp)]),
         "lfi_free_pinned": (i, [vp]),
         "lfi_grid_modified": (i, [vp]),
@@ -389,6 +390,11 @@ class Context:
         self._pinned.append(p.value)
         buf = (C.c_uint8 * nbytes).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def download_quilt_tiles(self, out: np.ndarray, tiles_x: int, tiles_y: int, first_tile: int, n: int, v0: int = 0) -> None:
+        """views v0 … v0+n-1 into tiles first_tile … of the quilt image `out` ((tiles_y·H, tiles_x·W, 4) uint8, C-contiguous)"""
+        assert out.dtype == np.uint8 and out.flags.c_contiguous and out.shape == (tiles_y * self.height, tiles_x * self.width, 4)
+        self._check(self._lib.lfi_download_quilt_tiles(self._h, tiles_x, tiles_y, first_tile, n, v0, _ptr(out), tiles_x * self.width * 4))
 
     def download_quilt(self, tiles_x: int, tiles_y: int, v0: int = 0) -> np.ndarray:
         out = np.empty((tiles_y * self.height, tiles_x * self.width, 4), dtype=np.uint8)

@@ -533,4 +533,44 @@ __global__ void __launch_bounds__(256) view_planar_to_rgba(const uint8_t *__rest
             rgba[(size_t)y * W + x4 + i] = ((c[0] >> (8 * i)) & 0xffu) | (((c[1] >> (8 * i)) & 0xffu) << 8) | (((c[2] >> (8 * i)) & 0xffu) << 16) | 0xff000000u;
 }
 
+// The quilt (scripts/viewsToQuilt.sh: `montage -tile 5x9` of the NN.png files) assembled on the device: views v0 … v0 + n − 1 of the context
+// become tiles first … first + n − 1 (row-major) of a quilt of tiles_x columns; `quilt` is the RGBA image of the quilt ROWS OF TILES that
+// these tiles touch (tile row first / tiles_x is its row 0), qw = tiles_x·W pixels wide.  PLANAR: the views are byte planes
+// [view][R,G,B][rows][pitch] and are expanded on the fly (alpha 255, uchar4{…, 255}: src/kernels.cu:393), else RGBA planes.
+// grid (ceil(W/4 / 256), rows, n); a lane moves four pixels.
+template <bool PLANAR>
+__global__ void __launch_bounds__(256) quilt_assemble(const uint8_t *__restrict__ views, uint32_t *__restrict__ quilt, const int W, const int rows, const int pitch,
+                                                      const size_t view_stride, const int v0, const int first, const int tiles_x)
+{
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if(x4 >= W)
+        return;
+    const int y = blockIdx.y, i = blockIdx.z;
+    const int tile = first + i, trow = tile / tiles_x - first / tiles_x, tcol = tile % tiles_x;
+    const uint8_t *view = views + (size_t)(v0 + i) * view_stride;
+    uint32_t px[4];
+    if constexpr(PLANAR)
+    {
+        uint32_t c[3];
+#pragma unroll
+        for(int ch = 0; ch < 3; ch++)
+            c[ch] = *reinterpret_cast<const uint32_t *>(view + ((size_t)ch * rows + y) * pitch + x4); // pitch is a multiple of 128
+#pragma unroll
+        for(int k = 0; k < 4; k++)
+            px[k] = ((c[0] >> (8 * k)) & 0xffu) | (((c[1] >> (8 * k)) & 0xffu) << 8) | (((c[2] >> (8 * k)) & 0xffu) << 16) | 0xff000000u;
+    }
+    else
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(view) + (size_t)y * W + x4;
+#pragma unroll
+        for(int k = 0; k < 4; k++)
+            px[k] = x4 + k < W ? src[k] : 0u;
+    }
+    uint32_t *dst = quilt + ((size_t)trow * rows + y) * ((size_t)tiles_x * W) + (size_t)tcol * W + x4;
+#pragma unroll
+    for(int k = 0; k < 4; k++)
+        if(x4 + k < W)
+            dst[k] = px[k];
+}
+
 } // namespace lfi

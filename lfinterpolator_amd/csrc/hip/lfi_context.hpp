@@ -57,6 +57,8 @@ struct lfi_ctx
     size_t rgba_scratch_bytes = 0;
     uint8_t *dl_plane = nullptr;       // planar layout: one RGBA plane that downloads expand a view into
     size_t dl_plane_bytes = 0;
+    uint8_t *quilt = nullptr;          // lfi_download_quilt[_tiles]: the quilt's rows of tiles as one RGBA image (grows, kept)
+    size_t quilt_bytes = 0;
     // parameter block
     bool have_params = false;
     int views_n = 0, k_pad = 0, v_pad = 0, n_focus_ids = 0;
@@ -391,6 +393,10 @@ void free_views(lfi_ctx *c)
         (void)hipFree(c->dl_plane);
     c->dl_plane = nullptr;
     c->dl_plane_bytes = 0;
+    if(c->quilt)
+        (void)hipFree(c->quilt);
+    c->quilt = nullptr;
+    c->quilt_bytes = 0;
     if(c->views2)
         (void)hipFree(c->views2);
     c->views2 = nullptr;

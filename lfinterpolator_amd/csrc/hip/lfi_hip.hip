@@ -1045,32 +1045,86 @@ int lfi_download_map(lfi_ctx *ctx, int k, uint8_t *rgba, size_t pitch_bytes)
     return LFI_OK;
 }
 
-int lfi_download_quilt(lfi_ctx *ctx, int tiles_x, int tiles_y, int v0, uint8_t *rgba, size_t pitch_bytes)
+int lfi_download_quilt_tiles(lfi_ctx *ctx, int tiles_x, int tiles_y, int first_tile, int n, int v0, uint8_t *rgba, size_t pitch_bytes)
 {
     if(!ctx)
         return LFI_EINVAL;
     if(!ctx->views || !ctx->have_params)
         return fail(ctx, LFI_EINVAL, "nothing rendered yet");
-    if(tiles_x < 1 || tiles_y < 1 || v0 < 0 || (long)v0 + (long)tiles_x * tiles_y > ctx->views_n)
-        return fail(ctx, LFI_EINVAL, "quilt needs tiles_x*tiles_y views starting at v0 inside [0, views)");
+    if(tiles_x < 1 || tiles_y < 1 || first_tile < 0 || n < 1 || (long)first_tile + n > (long)tiles_x * tiles_y || v0 < 0 || (long)v0 + n > ctx->views_n)
+        return fail(ctx, LFI_EINVAL, "quilt needs the tiles inside the quilt and as many views starting at v0 inside [0, views)");
     if(!rgba || pitch_bytes < (size_t)tiles_x * ctx->width * 4)
         return fail(ctx, LFI_EINVAL, "bad quilt pointer or pitch");
     if(int rc = bind(ctx))
         return rc;
-    // one strided device→host copy per tile straight into its place in the quilt: no staging buffer, no extra kernel
-    for(int ty = 0; ty < tiles_y; ty++)
-        for(int tx = 0; tx < tiles_x; tx++)
+    // The rows of tiles these tiles touch, assembled on the device by ONE kernel (planar views are expanded on the fly: no per-view
+    // conversion pass), then copied to the host in one rectangle — or three when the first / last row of tiles is only partly this
+    // context's (a trajectory sharded over several GPUs: every context fills its own tiles of the same host image).
+    const int tr0 = first_tile / tiles_x, tr1 = (first_tile + n - 1) / tiles_x;
+    const int W = ctx->width, rows = ctx->out_rows;
+    const size_t qrow = (size_t)tiles_x * W * 4;
+    const size_t need = qrow * rows * (size_t)(tr1 - tr0 + 1);
+    if(ctx->quilt_bytes < need)
+    {
+        if(ctx->quilt)
+            (void)hipFree(ctx->quilt);
+        ctx->quilt = nullptr;
+        ctx->quilt_bytes = 0;
+        LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->quilt), need));
+        ctx->quilt_bytes = need;
+    }
+    const dim3 grid(((W + 3) / 4 + 255) / 256, rows, n), block(256);
+    if(ctx->out_layout == LFI_LAYOUT_PLANAR_RGB)
+        hipLaunchKernelGGL(lfi::quilt_assemble<true>, grid, block, 0, ctx->stream, ctx->views, reinterpret_cast<uint32_t *>(ctx->quilt), W, rows, view_pitch(ctx),
+                           out_plane_bytes(ctx), v0, first_tile, tiles_x);
+    else
+        hipLaunchKernelGGL(lfi::quilt_assemble<false>, grid, block, 0, ctx->stream, ctx->views, reinterpret_cast<uint32_t *>(ctx->quilt), W, rows, 0,
+                           out_plane_bytes(ctx), v0, first_tile, tiles_x);
+    LFI_HIP(ctx, hipGetLastError());
+    const int c_first = first_tile % tiles_x, c_last = (first_tile + n - 1) % tiles_x;
+    // rows of tiles [ra, rb] × tile columns [ca, cb] → the host image (a row window: only the band's rows of every tile exist)
+    auto copy_rect = [&](int ra, int rb, int ca, int cb) -> hipError_t {
+        const size_t w_bytes = (size_t)(cb - ca + 1) * W * 4;
+        if(rows == ctx->height) // the tiles' rows are contiguous in the host image too: one copy for all rows of tiles
+            return hipMemcpy2DAsync(rgba + (size_t)ra * ctx->height * pitch_bytes + (size_t)ca * W * 4, pitch_bytes,
+                                    ctx->quilt + (size_t)(ra - tr0) * rows * qrow + (size_t)ca * W * 4, qrow, w_bytes, (size_t)(rb - ra + 1) * rows,
+                                    hipMemcpyDeviceToHost, ctx->stream);
+        for(int r = ra; r <= rb; r++)
         {
-            const int v = v0 + ty * tiles_x + tx;
-            uint8_t *dst = rgba + ((size_t)ty * ctx->height + ctx->out_y0) * pitch_bytes + (size_t)tx * ctx->width * 4;
-            const uint8_t *src = nullptr; // planar layout: expanded into the staging plane, which the copy below reads in stream order
-            if(int rc = rgba_plane_of_view(ctx, v, &src))
-                return rc;
-            LFI_HIP(ctx, hipMemcpy2DAsync(dst, pitch_bytes, src, (size_t)ctx->width * 4,
-                                          (size_t)ctx->width * 4, ctx->out_rows, hipMemcpyDeviceToHost, ctx->stream));
+            const hipError_t e = hipMemcpy2DAsync(rgba + ((size_t)r * ctx->height + ctx->out_y0) * pitch_bytes + (size_t)ca * W * 4, pitch_bytes,
+                                                  ctx->quilt + (size_t)(r - tr0) * rows * qrow + (size_t)ca * W * 4, qrow, w_bytes, rows, hipMemcpyDeviceToHost, ctx->stream);
+            if(e != hipSuccess)
+                return e;
         }
+        return hipSuccess;
+    };
+    if(tr0 == tr1)
+        LFI_HIP(ctx, copy_rect(tr0, tr0, c_first, c_last));
+    else
+    {
+        int full0 = tr0, full1 = tr1;
+        if(c_first != 0)
+        {
+            LFI_HIP(ctx, copy_rect(tr0, tr0, c_first, tiles_x - 1));
+            full0++;
+        }
+        if(c_last != tiles_x - 1)
+        {
+            LFI_HIP(ctx, copy_rect(tr1, tr1, 0, c_last));
+            full1--;
+        }
+        if(full0 <= full1)
+            LFI_HIP(ctx, copy_rect(full0, full1, 0, tiles_x - 1));
+    }
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LFI_OK;
+}
+
+int lfi_download_quilt(lfi_ctx *ctx, int tiles_x, int tiles_y, int v0, uint8_t *rgba, size_t pitch_bytes)
+{
+    if(ctx && (tiles_x < 1 || tiles_y < 1))
+        return fail(ctx, LFI_EINVAL, "quilt needs tiles_x*tiles_y views starting at v0 inside [0, views)");
+    return lfi_download_quilt_tiles(ctx, tiles_x, tiles_y, 0, tiles_x * tiles_y, v0, rgba, pitch_bytes);
 }
 
 int lfi_alloc_pinned(size_t bytes, void **out_ptr)

@@ -276,9 +276,14 @@ void Interpolator::storeResults(std::string path)
         std::cout << "Storing quilt..." << std::endl;
         const size_t quiltPitch = pitch * quiltTiles.x;
         std::vector<uint8_t> quilt(quiltPitch * resolution.y * quiltTiles.y);
-        if(gpuCount > 1)
-            throw std::runtime_error("The quilt output is available on a single GPU only!");
-        check(lfi_download_quilt(context, quiltTiles.x, quiltTiles.y, 0, quilt.data(), quiltPitch));
+        // every GPU assembles the tiles of ITS views on the device and copies them into their place in the one host image
+        const int tiles = quiltTiles.x * quiltTiles.y;
+        for(int g = 0; g < gpuCount; g++)
+        {
+            const int first = viewStart[g], last = std::min(g + 1 < gpuCount ? viewStart[g + 1] : viewCount, tiles);
+            if(first < last)
+                check(lfi_download_quilt_tiles(contexts[g], quiltTiles.x, quiltTiles.y, first, last - first, 0, quilt.data(), quiltPitch), contexts[g]);
+        }
         lfi::writePng((std::filesystem::path(path) / "quilt.png").string(), resolution.x * quiltTiles.x, resolution.y * quiltTiles.y,
                       static_cast<int>(channels), quilt.data(), quiltPitch);
     }

@@ -308,12 +308,18 @@ def test_row_band_sharding_matches_full_render(world, gpu, oracle_c):
     full.close()
 
 
-def test_quilt_download(gpu):
+@pytest.mark.parametrize("layout", ["rgba", "planar"])
+def test_quilt_download(layout, gpu):
+    """lfi_download_quilt: the views as ONE image of tiles, assembled on the device (one kernel, the planar layout expanded on the fly) and
+    copied in one rectangle: byte for byte the montage of the views' own downloads (scripts/viewsToQuilt.sh montages the NN.png files).
+    lfi_download_quilt_tiles: the same image filled by several contexts, each with the tiles of its views (a trajectory sharded over
+    GPUs) — ranges that start and end in the middle of a row of tiles — and under a row window."""
     cols = rows = 3
-    W, H, V = 40, 12, 10
+    W, H, V = 41, 12, 10                      # a width that is not a multiple of four
     hp = gpu.build_params(cols, rows, W, H, "0,0,1,1", 0.2, 0.0, 3.0, 1.0, V)
     ctx = _ctx(gpu, cols, rows, W, H, hp)
-    ctx.render("STD")
+    ctx.set_output_layout(layout)
+    ctx.render("TEN_WM")
     ctx.sync()
     views = ctx.download_views()
     quilt = ctx.download_quilt(4, 2, v0=1)
@@ -322,7 +328,41 @@ def test_quilt_download(gpu):
         assert (quilt[ty * H:(ty + 1) * H, tx * W:(tx + 1) * W] == views[1 + i]).all()
     with pytest.raises(gpu.LfiError, match="quilt needs"):
         ctx.download_quilt(4, 3)
+    # the same quilt from "three GPUs": contexts that hold views [0, 3), [3, 8), [8, 10) of the trajectory fill tiles 0-2, 3-7, 8-9 of a 5 x 2 quilt
+    want = ctx.download_quilt(5, 2)
     ctx.close()
+    got = np.zeros_like(want)
+    for v0, v1 in ((0, 3), (3, 8), (8, 10)):
+        part = _ctx(gpu, cols, rows, W, H, hp.rows(v0, v1))
+        part.set_output_layout(layout)
+        part.render("TEN_WM")
+        part.sync()
+        part.download_quilt_tiles(got, 5, 2, v0, v1 - v0)
+        with pytest.raises(gpu.LfiError, match="quilt needs"):
+            part.download_quilt_tiles(got, 5, 2, 9, 2)
+        part.close()
+    assert (got == want).all()
+    # a row window: only the band's rows of every tile are written
+    band = (3, 9)
+    win = gpu.Context(0)
+    win.set_grid(cols, rows, W, H)
+    in_rows = gpu.input_rows(band, hp.focused_offsets, H)
+    win.set_row_window(band[0], band[1], in_rows[0], in_rows[1])
+    win.fill_synthetic(SEED)
+    win.set_params(hp)
+    win.set_output_layout(layout)
+    win.render("TEN_WM")
+    win.sync()
+    got = np.zeros_like(want)
+    win.download_quilt_tiles(got, 5, 2, 2, 6, v0=2)
+    win.close()
+    for i in range(10):
+        ty, tx = divmod(i, 5)
+        tile = got[ty * H:(ty + 1) * H, tx * W:(tx + 1) * W]
+        if 2 <= i < 8:
+            assert (tile[band[0]:band[1]] == views[i][band[0]:band[1]]).all() and not tile[:band[0]].any() and not tile[band[1]:].any()
+        else:
+            assert not tile.any()
 
 
 def test_error_behaviour(gpu):
