@@ -134,7 +134,7 @@ namespace {
 // then had to keep every such block alive for the whole process, because contexts created after freed uncached ranges had been recycled as
 // ordinary memory rendered garbage (profiles/r03_notes.md section 6).  Round 3's own A/B (profiles/r03_views_memory_ab.txt) shows no gain
 // left from the placement outside box noise, so round 4 removed it together with the immortal pool: no allocation outlives its context.
-// Measurement builds (tools/views_mtype.py): LFI_VIEWS_MEMORY=uncached|finegrained still selects the other kinds for A/B runs.
+// Measurement builds: LFI_VIEWS_MEMORY=uncached|finegrained still selects the other kinds for A/B runs.
 hipError_t alloc_views(uint8_t **out, size_t bytes)
 {
 #ifdef LFI_MEASUREMENT_BUILD

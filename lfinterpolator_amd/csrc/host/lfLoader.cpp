@@ -13,37 +13,45 @@
 #include "image_io.h"
 #include "loadingbar.hpp"
 
+// The file names of a directory, ordered.  Error texts as the reference prints them (src/lfLoader.cpp:8-20).
 const std::set<std::filesystem::path> LfLoader::listPath(std::string path) const
 {
-    if(!std::filesystem::exists(path))
+    std::error_code ec;
+    const std::filesystem::file_status st = std::filesystem::status(path, ec);
+    if(ec || st.type() == std::filesystem::file_type::not_found)
         throw std::runtime_error("The path " + path + " does not exist!");
-    if(!std::filesystem::is_directory(path))
+    if(st.type() != std::filesystem::file_type::directory)
         throw std::runtime_error("The path " + path + " does not lead to a directory!");
-
-    std::set<std::filesystem::path> sorted;
-    for(const auto &file : std::filesystem::directory_iterator(path))
-        sorted.insert(file.path().filename());
-    return sorted;
+    std::set<std::filesystem::path> names;
+    for(std::filesystem::directory_iterator it(path, ec), end; !ec && it != end; it.increment(ec))
+        names.insert(it->path().filename());
+    if(ec)
+        throw std::runtime_error("The path " + path + " cannot be listed: " + ec.message());
+    return names;
 }
 
-// "<row>_<col>.<ext>": the first number is the vertical index, the second the horizontal one
-// (reference src/lfLoader.cpp:22-31; its help text says column_row but the code does this)
+// "<row>_<col>.<ext>": two decimal numbers around the first underscore, the first is the vertical index, the second the horizontal one
+// (what reference src/lfLoader.cpp:22-31 does; its help text says column_row).  Anything else — no underscore, no digits, trailing
+// characters before the extension — is refused with the reference's message.
 lfi::IVec2 LfLoader::parseFilename(std::string name) const
 {
-    auto delimiterPos = name.find('_');
-    if(delimiterPos == std::string::npos)
-        throw std::runtime_error("File " + name + " is not named properly as column_row.extension!");
-    auto extensionPos = name.find('.');
-    auto row = name.substr(0, delimiterPos);
-    auto col = name.substr(delimiterPos + 1, extensionPos == std::string::npos ? std::string::npos : extensionPos - delimiterPos - 1);
-    try
-    {
-        return {std::stoi(row), std::stoi(col)};
-    }
-    catch(const std::exception &)
-    {
-        throw std::runtime_error("File " + name + " is not named properly as column_row.extension!");
-    }
+    const auto refuse = [&]() -> lfi::IVec2 { throw std::runtime_error("File " + name + " is not named properly as column_row.extension!"); };
+    const auto number = [&](size_t &pos, int &out) {
+        const size_t start = pos;
+        long v = 0;
+        while(pos < name.size() && name[pos] >= '0' && name[pos] <= '9' && v < 100000000)
+            v = v * 10 + (name[pos++] - '0');
+        out = static_cast<int>(v);
+        return pos > start && v < 100000000;
+    };
+    size_t pos = 0;
+    int row = 0, col = 0;
+    if(!number(pos, row) || pos >= name.size() || name[pos] != '_')
+        return refuse();
+    pos++;
+    if(!number(pos, col) || (pos < name.size() && name[pos] != '.'))
+        return refuse();
+    return {row, col};
 }
 
 void LfLoader::loadImage(std::string path, lfi::IVec2 coords)

@@ -2,7 +2,7 @@
 (-DLFI_MEASUREMENT_BUILD) reads LFI_PLANAR_EXTRA_PITCH (bytes added to every plane row of the derived copy: the plane stride moves by
 1080 × that, every row start by a multiple of it); the views' pitch follows the width, so the output planes are skewed by rendering
 a narrower / wider image (W = 1920 ± 16·k changes the view plane stride by 1080·16·k bytes).  One process per setting.
-usage: LFI_AB_LIB=gpurun_ab/liblfi_meas.so LFI_PLANAR_EXTRA_PITCH=n python tools/plane_skew.py [W]"""
+usage: LFI_AB_LIB=<a library built with make HIPFLAGS+=-DLFI_MEASUREMENT_BUILD> LFI_PLANAR_EXTRA_PITCH=n python tools/plane_skew.py [W]"""
 import os, sys
 sys.path.insert(0, "."); sys.path.insert(0, "tools")
 import _ablib  # noqa: F401

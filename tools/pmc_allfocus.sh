@@ -1,5 +1,6 @@
 # FETCH_SIZE / WRITE_SIZE of the all-focus renders at config 5 (structured scene's estimated map, and a constant map): how much of the gather's
 # traffic is sector over-fetch?  (FETCH_SIZE x2 on gfx950 for wide coalesced streams — NOT calibrated for 4-byte gathers: both factors are printed.)
+: ${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for spec in "TEN_WM estimated" "TEN_WM constant" "STD estimated"; do
   set -- $spec

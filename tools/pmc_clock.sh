@@ -1,4 +1,5 @@
 # effective shader clock during a kernel: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / duration
+: ${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/pmc_clk/std -o p -- python3 tools/run_variants.py persist_m2_nt STD > gpurun_out/pmc_clk_std.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/pmc_clk/ten -o p -- python3 tools/run_variants.py persist_m2_nt TEN_WM > gpurun_out/pmc_clk_ten.log 2>&1

@@ -1,4 +1,5 @@
 # SQ counters of the focus-map passes at 4K (15x15 scene): where does focus_range's time go?
+: ${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAVES TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do

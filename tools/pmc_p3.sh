@@ -1,5 +1,6 @@
 # SQ counters of blend_p3 at a BASELINE config (separate passes), full kernel and the no-DMA ablation build; CONFIG=3 by default.
 # Then FETCH_SIZE / WRITE_SIZE of config 2 in both view layouts (gfx950: FETCH_SIZE x2 for coalesced streams, profiles/r01_hbm_traffic.md).
+: ${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 C=${CONFIG:-3}
 for abl in 0 2; do

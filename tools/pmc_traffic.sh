@@ -1,5 +1,6 @@
 # HBM bytes per launch of the default TEN_WM kernel (bench.py, config 2): FETCH_SIZE and WRITE_SIZE in separate passes (KiB;
 # gfx950: FETCH_SIZE x2, calibrated in profiles/r01_hbm_traffic.md), plus the calibration copy from tools/ablate.
+: ${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d gpurun_out/traffic/$c -o t -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 --prewarm-ms 0 > gpurun_out/traffic_$c.log 2>&1 || echo "$c failed"

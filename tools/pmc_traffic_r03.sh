@@ -1,6 +1,7 @@
 # Round 3: HBM-side bytes per launch (FETCH_SIZE x2 for coalesced streams on gfx950 — profiles/r01_hbm_traffic.md — and WRITE_SIZE, KiB,
 # separate passes) of the fixed-focus kernels with the single-plane derived copy: blend_p3 at configs 2, 3, 4 (rank), 5 and blend_stdx
 # (STD, RGBA views) at configs 3 and 5 — does the chain's second fetch reach HBM?
+: ${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for spec in "2 planar TEN_WM" "3 planar TEN_WM" "4 planar TEN_WM" "5 planar TEN_WM" "3 rgba STD" "5 rgba STD"; do
   set -- $spec

@@ -1,5 +1,6 @@
 # rocprofv3 --kernel-trace --stats per BASELINE configuration (round 3): the kernel-stats CSVs that back bench.py's `also` table.
 # Copies <name>_kernel_stats.csv into gpurun_out/prof_r03/; commit them under profiles/ as r03_<name>_kernel_stats.csv.
+: ${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof_r03
 run() { # name, command...

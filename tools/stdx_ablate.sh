@@ -1,5 +1,6 @@
 # Where does blend_stdx's time go?  Measurement builds of the library (-DLFI_SX_ABL=n, see blend_stdx.hpp) timed on one box by
 # tools/std15_time.py; run on the GPU box (hipcc is there too).  Results: gpurun_out/stdx_ablate.txt
+: ${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_ab gpurun_out
 for n in 1; do
