@@ -151,6 +151,16 @@ int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes);
  * window.  n == 1 is a no-op.  Synchronous.  (One process per GPU instead: broadcast the attached buffers with your own
  * communicator, as bench.py does through torch.distributed.) */
 int lfi_broadcast_grid(lfi_ctx *const *ctxs, int n, int root);
+/* Fixed-focus use only: make the derived planar copy of the inputs (3 bytes per pixel and image, built and tuned for the CURRENT
+ * parameters' offsets now if it is not yet) the ONLY copy and free the RGBA planes — the inputs' footprint drops from 1.9x to 0.9x of
+ * the RGBA bytes (BASELINE config 5: 14.2 -> 6.8 GB).  Afterwards: fixed-focus TEN_WM / STD renders through the default kernels are
+ * served as before, for any parameters whose offsets the copy's padding covers (it is padded a quarter beyond the current ones);
+ * lfi_upload_image[_async] replaces an image through a one-image staging plane (synchronously); everything that needs the RGBA planes
+ * — lfi_focus_map, all-focus renders, debug modes, weights outside [0, 2), larger offsets, lfi_fill_synthetic*, lfi_grid_device_ptr,
+ * lfi_broadcast_grid — is refused with LFI_EINVAL until lfi_set_grid / lfi_attach_grid start over.  An attached grid is only forgotten.
+ * The reference keeps its inputs as cudaArrays for the lifetime of the object (src/interpolator.cu:73-93, loadGPUData :95-137). */
+int lfi_release_inputs(lfi_ctx *ctx);
+
 /* device pointer / size of the input planes currently in use */
 int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes);
 /* Tell the library that the contents of the input planes changed behind its back (a write through lfi_grid_device_ptr, or into

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "lfi_create", "lfi_destroy", "lfi_last_error", "lfi_abi_version", "lfi_device_count", "lfi_set_grid", "lfi_set_row_window",
     "lfi_upload_image", "lfi_attach_grid", "lfi_broadcast_grid", "lfi_grid_device_ptr", "lfi_fill_synthetic", "lfi_set_params",
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
-    "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_download_quilt_tiles", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
+    "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_download_quilt_tiles", "lfi_release_inputs", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
     "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_fill_synthetic_scene", "lfi_upload_image_async", "lfi_upload_wait", "lfi_render_stream", "lfi_compare_view", "lfi_debug_mfma_f16_chain", "lfi_debug_pk_minmax3_f16",
 ]
@@ -109,6 +109,7 @@ def load_hip_library() -> C.CDLL:
         "lfi_sync": (i, [vp]),
         "lfi_download_view": (i, [vp, i, vp, sz]),
         "lfi_download_map": (i, [vp, i, vp, sz]),
+        "lfi_release_inputs": (i, [vp]),
         "lfi_download_quilt": (i, [vp, i, i, i, vp, sz]),
         "lfi_download_quilt_tiles": (i, [vp, i, i, i, i, i, vp, sz]),
         "lfi_alloc_pinned": (i, [sz, C.POINTER(vp)]),
@@ -241,6 +242,10 @@ class Context:
         p, n = C.c_void_p(), C.c_size_t()
         self._check(self._lib.lfi_grid_device_ptr(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def release_inputs(self) -> None:
+        """Fixed-focus use only: the planar copy becomes the only copy of the inputs, the RGBA planes are freed."""
+        self._check(self._lib.lfi_release_inputs(self._h))
 
     def grid_modified(self) -> None:
         """The input planes were written behind the library's back (attached buffer, raw device pointer)."""

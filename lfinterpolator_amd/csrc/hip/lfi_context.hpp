@@ -48,6 +48,10 @@ struct lfi_ctx
     uint8_t *grid = nullptr;
     bool own_grid = false;
     size_t grid_bytes = 0;
+    // lfi_release_inputs: the RGBA planes are gone, the derived planar copy is the only copy of the inputs (fixed-focus renders through
+    // the planar kernels only); a later lfi_upload_image goes through a one-image staging plane straight into the copy
+    bool inputs_released = false;
+    uint8_t *stage_plane = nullptr;
     uint8_t *maps = nullptr;
     uint8_t *views = nullptr;
     bool own_views = false;
@@ -414,6 +418,10 @@ void free_grid(lfi_ctx *c)
     c->grid = nullptr;
     c->own_grid = false;
     c->grid_bytes = 0;
+    c->inputs_released = false;
+    if(c->stage_plane)
+        (void)hipFree(c->stage_plane);
+    c->stage_plane = nullptr;
     if(c->maps)
         (void)hipFree(c->maps);
     c->maps = nullptr;

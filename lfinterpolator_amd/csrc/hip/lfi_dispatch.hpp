@@ -268,7 +268,7 @@ int check_render_args(lfi_ctx *c, int method, int v0, int v1)
 {
     if(!c)
         return LFI_EINVAL;
-    if(!c->grid)
+    if(!c->grid && !c->inputs_released)
         return fail(c, LFI_EINVAL, "lfi_set_grid has not been called");
     if(!c->have_params)
         return fail(c, LFI_EINVAL, "lfi_set_params has not been called");
@@ -317,6 +317,8 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     };
     if(valid && (!tune || tuned()))
         return true;
+    if(c->inputs_released)
+        return valid; // nothing to rebuild from: the copy serves the offsets it was built for (untuned phases only cost 3–5 %), or the render is refused
     // the copy in place fits and only SOME images were replaced since it was brought up to date (lfi_upload_image, a partial fill): their
     // planes only — 1/N of a rebuild per image
     if(c->planar && c->planar_version != 0 && c->planar_reach >= reach && (int)c->planar_phase.size() == c->n &&
@@ -428,7 +430,7 @@ bool tune_planar_now(lfi_ctx *c)
 // assembly repeats per view pass).
 bool wants_planar(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
 {
-    if(all_focus || a.prequant || !c->weights_scalable || a.v1 - a.v0 > std::max(c->n, 64))
+    if(all_focus || a.prequant || !c->weights_scalable || (a.v1 - a.v0 > std::max(c->n, 64) && !c->inputs_released))
         return false;
     if(method == LFI_METHOD_TEN_WM)
         return kTenVariants[c->ten_variant].planar && !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH);
@@ -562,6 +564,9 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
 {
     if(int rc = join_uploads(c))
         return rc;
+    if(c->inputs_released && !(wants_derived_copy(c, method, all_focus, a_in) && ensure_planar(c)))
+        return fail(c, LFI_EINVAL, "the RGBA inputs were released (lfi_release_inputs): only fixed-focus renders whose offsets the planar copy was built for "
+                                   "are served (no all-focus render, debug mode, weights outside [0, 2) or larger offsets) - upload the images again");
     if(c->out_layout != LFI_LAYOUT_PLANAR_RGB)
         return launch_blend_rgba(c, method, all_focus, a_in);
     if(wants_p3(c, method, all_focus, a_in) && ensure_planar(c, tune_planar_now(c)))

@@ -197,6 +197,7 @@ int lfi_set_row_window(lfi_ctx *ctx, int out_y0, int out_y1, int in_y0, int in_y
         (void)hipFree(ctx->grid);
     ctx->grid = nullptr;
     ctx->own_grid = false;
+    ctx->inputs_released = false;
     ctx->in_y0 = in_y0;
     ctx->in_rows = in_y1 - in_y0;
     ctx->out_y0 = out_y0;
@@ -214,7 +215,7 @@ int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_byte
 {
     if(!ctx)
         return LFI_EINVAL;
-    if(!ctx->grid)
+    if(!ctx->grid && !ctx->inputs_released)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
     if(g < 0 || g >= ctx->n || !rgba || pitch_bytes < (size_t)ctx->width * 4)
         return fail(ctx, LFI_EINVAL, "bad image index, pointer or pitch");
@@ -222,6 +223,21 @@ int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_byte
         return rc;
     if(int rc = join_uploads(ctx))
         return rc;
+    if(ctx->inputs_released)
+    {
+        // the RGBA planes are gone: the image goes through a one-image staging plane straight into its planes of the planar copy
+        if(!ctx->stage_plane)
+            LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->stage_plane), in_plane_bytes(ctx)));
+        LFI_HIP(ctx, hipMemcpy2DAsync(ctx->stage_plane, (size_t)ctx->width * 4, rgba + (size_t)ctx->in_y0 * pitch_bytes, pitch_bytes, (size_t)ctx->width * 4,
+                                      ctx->in_rows, hipMemcpyHostToDevice, ctx->stream));
+        // planar_build reads image g at grid + g·plane: hand it a base that puts the staging plane there
+        hipLaunchKernelGGL(lfi::planar_build, dim3((ctx->planar_pitch / 4 + 255) / 256, ctx->in_rows, 1), dim3(256), 0, ctx->stream,
+                           ctx->stage_plane - in_plane_bytes(ctx) * (size_t)g, ctx->planar, ctx->width, ctx->in_rows, ctx->planar_pitch, ctx->planar_padx,
+                           ctx->d_planar_phase, g);
+        LFI_HIP(ctx, hipGetLastError());
+        LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return LFI_OK;
+    }
     // rgba addresses row 0 of the whole image; only the rows this context holds are copied
     LFI_HIP(ctx, hipMemcpy2DAsync(ctx->grid + in_plane_bytes(ctx) * g, (size_t)ctx->width * 4, rgba + (size_t)ctx->in_y0 * pitch_bytes,
                                   pitch_bytes, (size_t)ctx->width * 4, ctx->in_rows, hipMemcpyHostToDevice, ctx->stream));
@@ -234,6 +250,8 @@ int lfi_upload_image_async(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitc
 {
     if(!ctx)
         return LFI_EINVAL;
+    if(ctx->inputs_released)
+        return lfi_upload_image(ctx, g, rgba, pitch_bytes); // released inputs: through the staging plane, synchronously
     if(!ctx->grid)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
     if(g < 0 || g >= ctx->n || !rgba || pitch_bytes < (size_t)ctx->width * 4)
@@ -292,6 +310,7 @@ int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes)
         (void)hipFree(ctx->grid);
     ctx->grid = static_cast<uint8_t *>(device_ptr);
     ctx->own_grid = false;
+    ctx->inputs_released = false;
     ctx->grid_bytes = bytes;
     touch_all(ctx);
     ctx->grid_tracked = false; // the caller writes this buffer itself: see lfi_grid_modified
@@ -370,6 +389,31 @@ int lfi_broadcast_grid(lfi_ctx *const *ctxs, int n, int root)
     return status;
 }
 
+int lfi_release_inputs(lfi_ctx *ctx)
+{
+    if(!ctx)
+        return LFI_EINVAL;
+    if(ctx->inputs_released)
+        return LFI_OK;
+    if(!ctx->grid || !ctx->have_params)
+        return fail(ctx, LFI_EINVAL, "lfi_set_grid / lfi_set_params have not been called");
+    if(int rc = bind(ctx))
+        return rc;
+    if(int rc = lfi_upload_wait(ctx))
+        return rc;
+    // the planar copy, complete and tuned for the current offsets, becomes the only copy of the inputs
+    if(!ensure_planar(ctx, true))
+        return fail(ctx, LFI_EINVAL, "the planar copy of the inputs cannot be built (inputs the library does not track, absurd offsets, out of memory)");
+    LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if(ctx->own_grid && ctx->grid)
+        LFI_HIP(ctx, hipFree(ctx->grid));
+    ctx->grid = nullptr;
+    ctx->own_grid = false;
+    ctx->grid_bytes = 0;
+    ctx->inputs_released = true;
+    return LFI_OK;
+}
+
 int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes)
 {
     if(!ctx || !out_ptr)
@@ -388,6 +432,8 @@ int lfi_grid_modified(lfi_ctx *ctx)
 {
     if(!ctx)
         return LFI_EINVAL;
+    if(ctx->inputs_released)
+        return fail(ctx, LFI_EINVAL, "the RGBA inputs were released (lfi_release_inputs): lfi_set_grid and upload the images again");
     if(!ctx->grid)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
     touch_all(ctx);
@@ -399,6 +445,8 @@ int lfi_fill_synthetic_images(lfi_ctx *ctx, uint32_t seed, int g0, int g1)
 {
     if(!ctx)
         return LFI_EINVAL;
+    if(ctx->inputs_released)
+        return fail(ctx, LFI_EINVAL, "the RGBA inputs were released (lfi_release_inputs): lfi_set_grid and upload the images again");
     if(!ctx->grid)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid has not been called");
     if(g0 < 0 || g1 > ctx->n || g0 > g1)
@@ -420,6 +468,8 @@ int lfi_fill_synthetic_scene(lfi_ctx *ctx, uint32_t seed)
 {
     if(!ctx)
         return LFI_EINVAL;
+    if(ctx->inputs_released)
+        return fail(ctx, LFI_EINVAL, "the RGBA inputs were released (lfi_release_inputs): lfi_set_grid and upload the images again");
     if(!ctx->grid || !ctx->have_params)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid / lfi_set_params have not been called (the scene is built from the images' offsets)");
     if(int rc = bind(ctx))
@@ -672,6 +722,8 @@ int lfi_focus_map(lfi_ctx *ctx)
 {
     if(!ctx)
         return LFI_EINVAL;
+    if(ctx->inputs_released)
+        return fail(ctx, LFI_EINVAL, "the RGBA inputs were released (lfi_release_inputs): the focus map needs them - upload the images again (lfi_set_grid)");
     if(!ctx->grid || !ctx->have_params)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid / lfi_set_params have not been called");
     if(ctx->n_focus_ids < 1)
@@ -1238,6 +1290,8 @@ int lfi_download_coords(lfi_ctx *ctx, int g, int all_focus, int map_index, lfi_i
 {
     if(!ctx)
         return LFI_EINVAL;
+    if(ctx->inputs_released)
+        return fail(ctx, LFI_EINVAL, "the RGBA inputs were released (lfi_release_inputs): lfi_set_grid and upload the images again");
     if(!ctx->grid || !ctx->have_params)
         return fail(ctx, LFI_EINVAL, "lfi_set_grid / lfi_set_params have not been called");
     if(g < 0 || g >= ctx->n || !out_hw || map_index < 0 || map_index > 1)

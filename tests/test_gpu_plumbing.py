@@ -490,3 +490,78 @@ def test_replaced_images_refresh_only_their_planes(gpu, oracle_c):
     cur[4:9] = oracle_c.synthetic_lf(n, W, H, 0x55)[4:9]
     check(cur, "partial fill")
     ctx.close()
+
+
+@pytest.mark.parametrize("cols,rows,V", [(5, 3, 8), (13, 13, 70)])
+def test_release_inputs(cols, rows, V, gpu, oracle_c):
+    """lfi_release_inputs: the planar copy becomes the only copy of the inputs (round 4; the reference keeps its cudaArrays for the object's
+    lifetime, src/interpolator.cu:73-137).  Fixed-focus STD (bit-exact) and TEN_WM (≤ 1 LSB of M16) still match the oracle in both view
+    layouts and for parameters with smaller offsets; an image uploaded afterwards replaces its planes through the staging plane; what needs
+    the RGBA planes is refused; the footprint of the inputs is below 1.1× the RGBA bytes; lfi_set_grid starts over."""
+    W, H = 200, 24
+    n = cols * rows
+    hp = gpu.build_params(cols, rows, W, H, "0.1,0.2,0.8,0.9", 0.25, 0.17, 2.0, 1.5, V)
+    hp_small = gpu.build_params(cols, rows, W, H, "0.1,0.2,0.8,0.9", 0.11, 0.17, 2.0, 1.5, V)       # smaller offsets: the padding covers them
+    hp_large = gpu.build_params(cols, rows, W, H, "0.1,0.2,0.8,0.9", 0.9, 0.17, 2.0, 1.5, V)        # larger ones: it does not
+    assert np.abs(hp_small.focused_offsets[:, 0]).max() < np.abs(hp.focused_offsets[:, 0]).max() * 1.2 < np.abs(hp_large.focused_offsets[:, 0]).max()
+    lf = oracle_c.synthetic_lf(n, W, H, 31)
+    other = oracle_c.synthetic_lf(n, W, H, 32)
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    ctx.upload_grid(lf)
+    ctx.set_params(hp)
+    rgba_bytes = ctx.memory_info().grid_bytes
+    assert rgba_bytes == n * W * H * 4
+    ctx.release_inputs()
+    ctx.release_inputs()                         # idempotent
+    mem = ctx.memory_info()
+    assert mem.grid_bytes == 0 and 0 < mem.derived_bytes
+
+    def check(cur, p, what):
+        for layout in ("rgba", "planar"):
+            ctx.set_output_layout(layout)
+            ctx.render("STD"); ctx.sync()
+            assert (ctx.download_views() == oracle_c.blend_std(cur, p.focused_offsets, p.offsets, p.weights, threads=8)).all(), (what, layout, "STD")
+            ctx.render("TEN_WM"); ctx.sync()
+            m16 = oracle_c.blend_ten(cur, p.focused_offsets, p.offsets, p.weights, model=oracle_c.TEN_M16, threads=8)
+            assert np.abs(ctx.download_views().astype(int) - m16.astype(int)).max() <= 1, (what, layout, "TEN_WM")
+        ctx.set_output_layout("rgba")
+
+    check(lf, hp, "released")
+    ctx.set_params(hp_small)
+    check(lf, hp_small, "released, smaller offsets")
+    cur = lf.copy()
+    for g in (0, n - 1, n // 2):                 # replaced images go through the staging plane into the copy
+        cur[g] = other[g]
+        ctx.upload_image(g, other[g])
+    check(cur, hp_small, "released, images replaced")
+    ctx.set_params(hp)
+    check(cur, hp, "released, back to the first offsets")
+    # what needs the RGBA planes is refused
+    for call in (lambda: ctx.render("TEN_WM", all_focus=True), lambda: ctx.focus_map(), lambda: ctx.fill_synthetic(1), lambda: ctx.download_coords(0)):
+        with pytest.raises(gpu.LfiError, match="released"):
+            call()
+    ctx.set_variant("TEN_WM", "persist_m2_nt")   # a kernel that reads the RGBA planes
+    with pytest.raises(gpu.LfiError, match="released"):
+        ctx.render("TEN_WM")
+    ctx.set_variant("TEN_WM", "auto")
+    ctx.set_params(hp_large)
+    with pytest.raises(gpu.LfiError, match="released"):
+        ctx.render("TEN_WM")
+    # starting over
+    ctx.set_grid(cols, rows, W, H)
+    ctx.upload_grid(cur)
+    ctx.set_params(hp_large)
+    ctx.render("STD", all_focus=False); ctx.sync()
+    assert (ctx.download_views() == oracle_c.blend_std(cur, hp_large.focused_offsets, hp_large.offsets, hp_large.weights, threads=8)).all()
+    ctx.close()
+    # the footprint at a BASELINE-like width (padding is relative to the offsets, not to the image count)
+    ctx = gpu.Context(0)
+    ctx.set_grid(8, 8, 1920, 64)
+    ctx.fill_synthetic(SEED)
+    ctx.set_params(gpu.build_params(8, 8, 1920, 64, "0,0,1,1", 0.23, 0.0, 3.0, 1.783, 8))
+    before = ctx.memory_info()
+    ctx.release_inputs()
+    after = ctx.memory_info()
+    assert after.grid_bytes + after.derived_bytes <= 1.1 * before.grid_bytes, (before, after)
+    ctx.close()
