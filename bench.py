@@ -114,8 +114,15 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         n = n_images if n_images is not None else cfg["cols"] * cfg["rows"]
         ba = b_alg(cfg["W"], cfg["H"], n, cfg["H"], views) + in_bytes_extra
         fa = 6.0 * n * views * cfg["W"] * cfg["H"]
+        # `frac` as on the headline: the bytes the kernel has to MOVE in the layouts in use — 3 B per pixel and image for the kernels that
+        # read the alpha-free planar copy, 3 B per pixel and view for blend_p3's planar views, 4 B on RGBA sides — ÷ time ÷ 8 TB/s; the
+        # fraction on SURVEY.md's 4·W·H·(N + V) is kept as `frac_algorithmic` (round 3 printed that one as `frac` here: ADVICE r3)
+        in_bpp = 3 if any(k in kernel for k in ("blend_p3", "blend_planar", "blend_stdx<")) else 4
+        out_bpp = 3 if "blend_p3" in kernel else 4
+        bm = 1.0 * cfg["W"] * cfg["H"] * (in_bpp * n + out_bpp * views) + in_bytes_extra
         e = {"workload": f"{cfg['cols']}x{cfg['rows']} LF @{cfg['W']}x{cfg['H']}, {views} views", "kernel": kernel, "ms": ms,
-             "views_per_s": views / ms * 1e3, "algorithmic_bytes": ba, "hbm_gbs": ba / ms / 1e6, "frac": ba / ms / 1e6 / HBM_PEAK_GBS}
+             "views_per_s": views / ms * 1e3, "algorithmic_bytes": ba, "moved_bytes": bm, "hbm_gbs": bm / ms / 1e6, "frac": bm / ms / 1e6 / HBM_PEAK_GBS,
+             "frac_algorithmic": ba / ms / 1e6 / HBM_PEAK_GBS}
         if flops_bound:
             e["bound"] = "fp32"
             e["fp32_tflops"] = fa / ms / 1e9
@@ -298,6 +305,37 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
                                                 f"a fresh context's first render, caches flushed, one sweep direction: includes whatever the "
                                                 f"library derives from the inputs first ({mem.derived_bytes / 1e6:.0f} MB derived copy); median of 3")
             out[key + "_cold_one_shot"]["reps_ms"] = [round(r, 3) for r in res]   # a first hipMalloc of gigabytes can take 100+ ms on a box
+        # The same first render when the application said at load time what it will render (lfi_prepare: the derived copy is built as the
+        # images arrive, outside any render) and released the RGBA planes (lfi_release_inputs: the copy is the only copy of the inputs):
+        # a launch on cold caches, and the inputs' footprint
+        cfg = CONFIGS[5]
+        res = []
+        for rep in range(3):
+            ctx, hp = make_ctx(cfg, rng=0.0)
+            ctx.set_params(hp, flags=L.LFI_FLAG_SINGLE_SWEEP_DIRECTION)
+            if layout != "rgba":
+                ctx.set_output_layout(layout)
+            before = ctx.memory_info()
+            ctx.prepare("TEN_WM")
+            ctx.release_inputs()
+            ctx.sync()
+            flush.fill_(rep)
+            torch.cuda.synchronize()
+            ctx.timer_start()
+            ctx.render("TEN_WM")
+            res.append(ctx.timer_stop())
+            k = ctx.last_kernel_name()
+            after = ctx.memory_info()
+            if rep == 2:
+                steady = timed(ctx, lambda: ctx.render("TEN_WM"), max(2, iters // 2))
+            ctx.close()
+        e = entry(cfg, sorted(res)[1], cfg["views"], k, "a prepared context's first render (lfi_prepare + lfi_release_inputs at load time), caches flushed, one sweep direction; median of 3")
+        e["reps_ms"] = [round(r, 3) for r in res]
+        e["inputs_bytes_rgba"] = before.grid_bytes
+        e["inputs_bytes_after_release"] = after.grid_bytes + after.derived_bytes
+        e["inputs_footprint_vs_rgba"] = (after.grid_bytes + after.derived_bytes) / before.grid_bytes
+        e["steady_ms_released"] = steady
+        out["config5_cold_first_render_prepared"] = e
         del flush
 
     guarded(cold_one_shot)
@@ -443,7 +481,6 @@ def main() -> int:
     views = None
     if args.layout == "rgba":
         # RGBA views in a caller-owned torch tensor (the interop path); the planar layout keeps the library's own allocation, which
-        # is uncached device memory (write-only planes that bypass the caches leave the Infinity Cache to the inputs)
         views = torch.empty((views_per_gpu * ctx.view_layout().view_stride_bytes,), dtype=torch.uint8, device=dev)
         ctx.attach_views(views.data_ptr(), views.numel())
     ctx.set_variant(args.method, args.variant)
@@ -514,7 +551,7 @@ def main() -> int:
                        "views_per_gpu": views_per_gpu, "images": n_images, "variant": args.variant, "kernel": kernel_name,
                        "view_layout": ("RGBA planes (the reference's)" if args.layout == "rgba" else
                                        "alpha-free byte planes [view][R,G,B][H][W] (opt-in, lfi_set_output_layout; alpha = 255 is re-created "
-                                       "on download); library-owned, in uncached device memory"),
+                                       "on download)"),
                        "sweep": "consecutive launches walk the image in opposite directions (input rows read last are read first by the next "
                                 "launch: Infinity Cache reuse; LFI_FLAG_SINGLE_SWEEP_DIRECTION disables, timed in `also`)",
                        "inputs": ("resident in HBM before the timed region: RGBA planes + the derived planar alpha-free copy the kernel "
@@ -576,8 +613,9 @@ def main() -> int:
                 if isinstance(detail.get(key), dict):
                     line["roofline"][name] = detail[key]["ms"]
             # LAST on the line, compact, so that a reader who keeps only the tail of the output still has every configuration:
-            # [ms per launch, fraction of the bound (HBM 8 TB/s on 4·W·H·(N+V) bytes, or fp32 157.3 TFLOP/s where the kernel is fp32-bound), kernel]
-            compact = {"legend": "[ms, frac of 8 TB/s on 4WH(N+V) bytes | 'fp32:' frac of 157.3 TFLOP/s, kernel]"}
+            # [ms per launch, fraction of the bound (HBM 8 TB/s on the bytes MOVED in the layouts in use — as the headline's roofline.frac —, or
+            # fp32 157.3 TFLOP/s where the kernel is fp32-bound), kernel]; the fraction on 4·W·H·(N+V) bytes is also_detail's frac_algorithmic
+            compact = {"legend": "[ms, frac of 8 TB/s on the layout bytes moved (3 B/px alpha-free sides, 4 B/px RGBA sides) | 'fp32:' frac of 157.3 TFLOP/s, kernel]"}
             for key, e in detail.items():
                 if isinstance(e, dict) and "ms" in e:
                     fr = f"fp32:{e['fp32_frac']:.3f}" if e.get("bound") == "fp32" else round(e.get("frac", 0.0), 3)

@@ -52,6 +52,9 @@ struct lfi_ctx
     // the planar kernels only); a later lfi_upload_image goes through a one-image staging plane straight into the copy
     bool inputs_released = false;
     uint8_t *stage_plane = nullptr;
+    // set by lfi_prepare for a render that reads the planar copy: from then on images that arrive (lfi_upload_image, lfi_fill_synthetic_images)
+    // refresh their planes of the copy AT ONCE instead of at the next render — the first render after a load is then only a launch
+    bool eager_planar = false;
     uint8_t *maps = nullptr;
     uint8_t *views = nullptr;
     bool own_views = false;
@@ -419,6 +422,7 @@ void free_grid(lfi_ctx *c)
     c->own_grid = false;
     c->grid_bytes = 0;
     c->inputs_released = false;
+    c->eager_planar = false;
     if(c->stage_plane)
         (void)hipFree(c->stage_plane);
     c->stage_plane = nullptr;

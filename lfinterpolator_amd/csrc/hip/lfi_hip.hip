@@ -243,6 +243,8 @@ int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_byte
                                   pitch_bytes, (size_t)ctx->width * 4, ctx->in_rows, hipMemcpyHostToDevice, ctx->stream));
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     touch_images(ctx, g, g + 1);
+    if(ctx->eager_planar && ctx->have_params)
+        (void)ensure_planar(ctx); // this image's planes of the derived copy, now (stream-ordered; a failure leaves it to the next render)
     return LFI_OK;
 }
 
@@ -461,6 +463,8 @@ int lfi_fill_synthetic_images(lfi_ctx *ctx, uint32_t seed, int g0, int g1)
     hipLaunchKernelGGL(lfi::fill_synthetic, dim3(256 * 16), dim3(256), 0, ctx->stream, ctx->grid, g0, g1 - g0, ctx->width,
                        ctx->in_rows, ctx->in_y0, seed);
     LFI_HIP(ctx, hipGetLastError());
+    if(ctx->eager_planar && ctx->have_params)
+        (void)ensure_planar(ctx); // as lfi_upload_image
     return LFI_OK;
 }
 
@@ -803,6 +807,7 @@ int lfi_prepare(lfi_ctx *ctx, int method, int all_focus, int v0, int v1)
     ctx->derived_build_ms = 0.0f;
     if(wants_derived_copy(ctx, method, all_focus, a)) // the same predicate chain as launch_blend
     {
+        ctx->eager_planar = true; // images that arrive from now on refresh their planes of the copy at once
         const uint64_t before = ctx->planar_version;
         LFI_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         const bool ok = ensure_planar(ctx, true);
