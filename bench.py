@@ -201,6 +201,15 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
             ctx.set_output_layout(layout)
         ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters, prepare=("TEN_WM",))
         out["config4_rank"] = entry(c4, ms, v1 - v0, ctx.last_kernel_name(), f"rank 3 of 8: views [{v0},{v1}) of the 256-view trajectory")
+        # what one rank of a G-GPU run of config 4 launches, for the prediction of the 1/2/4/8 curve in DESIGN.md §8 (the 8-GPU rank is the
+        # entry above; G = 1 is config4_whole_1gpu below): aggregate views/s = 256 / (this time), if the ranks do not disturb each other
+        for G in (2, 4):
+            hp_g, g0, g1 = L.rank_params(c4["cols"], c4["rows"], c4["W"], c4["H"], c4["traj"], c4["focus"], 0.0, c4["effect"], c4["aspect"], 256, G, G // 2)
+            ctx.set_params(hp_g)
+            if layout != "rgba":
+                ctx.set_output_layout(layout)
+            ms_g = timed(ctx, lambda: ctx.render("TEN_WM"), max(2, iters // 2), prepare=("TEN_WM",))
+            out[f"config4_rank_of_{G}"] = entry(c4, ms_g, g1 - g0, ctx.last_kernel_name(), f"rank {G // 2} of {G}: views [{g0},{g1}) of the 256-view trajectory")
         hp_all = L.build_params(c4["cols"], c4["rows"], c4["W"], c4["H"], c4["traj"], c4["focus"], 0.0, c4["effect"], c4["aspect"], 256)
         ctx.set_params(hp_all)
         if layout != "rgba":
@@ -397,6 +406,13 @@ def main() -> int:
     # device).  The real multi-GPU run is one rank per GPU over RCCL ("nccl").
     rehearse = os.environ.get("LFI_BENCH_REHEARSE") == "1"
     device_index = 0 if rehearse else local_rank
+    # fail fast, with a message that says what is missing (a rank that dies inside set_device / NCCL init otherwise reads as a hang or a
+    # stack trace from the launcher): one GPU per rank …
+    n_dev = torch.cuda.device_count()
+    if not rehearse and n_dev < max(world, local_rank + 1):
+        print(f"bench.py: --gpus {world} needs {world} visible GPUs, this node shows {n_dev} (rank {rank}, LOCAL_RANK {local_rank}); "
+              f"run with --gpus {n_dev}, or set LFI_BENCH_REHEARSE=1 to rehearse the ranks on one GPU over gloo", file=sys.stderr)
+        return 3
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     # LFI_BENCH_FORCE_DIST=1: run the process group, the collectives and the barriers with ONE rank too — the only way to execute the
@@ -405,10 +421,23 @@ def main() -> int:
     if collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        try:
+            if rehearse:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                # … and a communicator that works: RCCL creates it lazily, so run one tiny all-reduce NOW — a node whose ranks cannot reach each
+                # other (IPC mode, missing xGMI / PCIe peer access, a dead rank) fails here, in set-up, not in the middle of the timed region
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all-reduce over {world} ranks returned {probe.item()}")
+        except Exception as e:
+            print(f"bench.py: rank {rank} of {world} could not initialise the process group over {'gloo' if rehearse else 'RCCL (backend nccl)'}: "
+                  f"{type(e).__name__}: {e}  [MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} "
+                  f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}]", file=sys.stderr)
+            return 4
 
     cfg = CONFIGS[args.config]
     COLS, ROWS, WIDTH, HEIGHT = cfg["cols"], cfg["rows"], cfg["W"], cfg["H"]

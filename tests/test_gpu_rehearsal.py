@@ -71,3 +71,17 @@ def test_two_rank_rehearsal_default_run(gpu):
     assert line["metric"].startswith("novel views/sec") and line["unit"] == "views/s" and line["higher_is_better"] is True
     assert line["value"] > 0 and abs(line["value"] - 128 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]   # both ranks' views
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1.0 and line["vs_baseline"] is None
+
+
+def test_more_ranks_than_gpus_fail_fast(gpu):
+    """`bench.py --gpus N` on a node with fewer GPUs (no rehearsal mode): every rank stops in set-up with a message that names the GPU
+    count, instead of dying inside set_device / the RCCL initialisation (round 4)."""
+    import torch
+    n = torch.cuda.device_count()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE=str(n + 1), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.pop("LFI_BENCH_REHEARSE", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert res.returncode == 3, (res.returncode, res.stderr[-1000:])
+    assert f"needs {n + 1} visible GPUs, this node shows {n}" in res.stderr
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
