@@ -644,7 +644,7 @@ def main() -> int:
             # LAST on the line, compact, so that a reader who keeps only the tail of the output still has every configuration:
             # [ms per launch, fraction of the bound (HBM 8 TB/s on the bytes MOVED in the layouts in use — as the headline's roofline.frac —, or
             # fp32 157.3 TFLOP/s where the kernel is fp32-bound), kernel]; the fraction on 4·W·H·(N+V) bytes is also_detail's frac_algorithmic
-            compact = {"legend": "[ms, frac of 8 TB/s on the layout bytes moved (3 B/px alpha-free sides, 4 B/px RGBA sides) | 'fp32:' frac of 157.3 TFLOP/s, kernel]"}
+            compact = {"legend": "[ms, frac of 8 TB/s on layout bytes moved | 'fp32:' frac of 157.3 TFLOP/s, kernel]"}
             for key, e in detail.items():
                 if isinstance(e, dict) and "ms" in e:
                     fr = f"fp32:{e['fp32_frac']:.3f}" if e.get("bound") == "fp32" else round(e.get("frac", 0.0), 3)

@@ -135,7 +135,7 @@ def test_bench_json_contract(gpu):
         assert key in detail and detail[key]["ms"] > 0 and 0 < detail[key]["frac"] < 1.2 and detail[key]["kernel"], key
         assert also[key][0] == round(detail[key]["ms"], 4), key
     assert detail["config5_fixed_focus_std_nontensor"]["kernel"] == "blend_std_vfma" and detail["config5_allfocus_std_nontensor"]["kernel"] == "blend_std_vfma"
-    assert len(json.dumps(also)) < 2000          # fits the tail a log reader keeps
+    assert len(json.dumps(also)) < 2400          # fits the tail a log reader keeps
 
 
 def test_pinned_host_buffers(gpu, oracle_c):
