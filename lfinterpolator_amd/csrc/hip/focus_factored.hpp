@@ -62,19 +62,9 @@ struct FocusWork
     uint16_t *K;        // [32][H][W]        exact keys of flagged (pixel, candidate) pairs
     int32_t We_p, He_p; // pitches of E: W + 2rx rounded up to 256, H + 2ry rounded up to 4
     int64_t *deltas;    // [32][32]  byte offset of (slot k's padded plane, row sy, column sx) from the padded base
-    uint8_t *pad;       // [n_ids][Hp][Wp][3]  padded copies, ALPHA-FREE (round 4): pad[k][yy][xx] = RGB of I_ids[k][clamp(yy − Py)][clamp(xx − Px)]
+    uint32_t *pad;      // [n_ids][Hp][Wp]  padded copies: pad[k][yy][xx] = I_ids[k][clamp(yy − Py)][clamp(xx − Px)]
     int32_t Wp, Hp, Px, Py;
 };
-
-// Bytes per pixel of the padded planes.  Rounds 1–3 kept RGBA dwords; the range pass is bound by L1 tag accesses (one per CU and cycle for
-// 94 % of the kernel, profiles/r03_pmc_focus_range_summary.txt) and a wave's four-pixel-per-lane load touches ≈ 19.5 sectors as 768 bytes
-// of packed RGB against 24 as 1 KB of RGBA: every pass over the planes moves a quarter fewer bytes through the L1.  A pixel is the three
-// bytes at 3·index: loads start at any byte address (legal for global loads in the unaligned access mode ROCm runs in; LDS-DMA from byte
-// addresses was probed in round 3), a one-pixel load reads a dword and ignores its top byte (the planes end with 4 spare bytes).
-constexpr int FOCUS_PAD_BPP = 3;
-typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-typedef uint32_t u32x3_a1 __attribute__((ext_vector_type(3), aligned(1)));
-typedef uint32_t u32_a1 __attribute__((aligned(1)));
 
 typedef const __attribute__((address_space(4))) int64_t *focus_const_i64_ptr;
 
@@ -107,7 +97,7 @@ __global__ void __launch_bounds__(1024) focus_plan_shifts(const KernelArgs a, co
     dst[1] = static_cast<int>(floor(static_cast<double>(f) * static_cast<double>(off.y)));
     dst[2] = g;
     dst[3] = 0;
-    w.deltas[i * FOCUS_MAX_IDS + k] = (((int64_t)k * w.Hp + dst[1]) * w.Wp + dst[0]) * FOCUS_PAD_BPP;
+    w.deltas[i * FOCUS_MAX_IDS + k] = (((int64_t)k * w.Hp + dst[1]) * w.Wp + dst[0]) * 4;
 }
 
 // pad[k][yy][xx] = I_ids[k][clamp(yy − Py)][clamp(xx − Px)]; grid (ceil(Wp/256), Hp, n_ids), a lane writes 4 pixels
@@ -132,12 +122,7 @@ __global__ void __launch_bounds__(64) focus_pad(const KernelArgs a, const FocusW
         v.z = row[clampi(x + 2, 0, W - 1)];
         v.w = row[clampi(x + 3, 0, W - 1)];
     }
-    // four RGBA pixels → twelve bytes R0 G0 B0 R1 … B3 (Wp is a multiple of 4: the twelve bytes start on a dword)
-    u32x3 o;
-    o.x = __builtin_amdgcn_perm(v.y, v.x, 0x04020100u);                                   // R0 G0 B0 R1
-    o.y = __builtin_amdgcn_perm(v.z, __builtin_amdgcn_perm(v.y, v.y, 0x0c0c0201u), 0x05040100u); // G1 B1 R2 G2
-    o.z = __builtin_amdgcn_perm(v.w, v.z, 0x06050402u);                                   // B2 R3 G3 B3
-    *reinterpret_cast<u32x3 *>(w.pad + (((size_t)k * w.Hp + yy) * w.Wp + xx) * FOCUS_PAD_BPP) = o;
+    *reinterpret_cast<u32x4 *>(w.pad + ((size_t)k * w.Hp + yy) * w.Wp + xx) = v; // Wp is a multiple of 4
 }
 
 // grid (ceil(max(W,H)/256), 32 candidates, 2 axes): is the uniform shift exact for this column / row?
@@ -331,42 +316,6 @@ struct RangeAcc4
             hi[p][2] = max3_bytes(hi[p][2], ab, bb);
         }
     }
-    // the same from twelve bytes of packed RGB per view (four pixels R0 G0 B0 R1 … B3 in three dwords): one v_perm_b32 per channel pair
-    // as before — pixels (0, 1): R = bytes 0, 3; G = 1, 4; B = 2, 5; pixels (2, 3): R = 6, 9; G = 7, 10; B = 8, 11
-    template <int P, int CH>
-    static __device__ __forceinline__ u16x2 rgb24_pair(const u32x3 v)
-    {
-        if constexpr(P == 0)
-            return as_u16x2(CH == 0 ? __builtin_amdgcn_perm(v.x, v.x, 0x0c030c00u) : (CH == 1 ? __builtin_amdgcn_perm(v.y, v.x, 0x0c040c01u) : __builtin_amdgcn_perm(v.y, v.x, 0x0c050c02u)));
-        else
-            return as_u16x2(CH == 0 ? __builtin_amdgcn_perm(v.z, v.y, 0x0c050c02u) : (CH == 1 ? __builtin_amdgcn_perm(v.z, v.y, 0x0c060c03u) : __builtin_amdgcn_perm(v.z, v.z, 0x0c030c00u)));
-    }
-    __device__ __forceinline__ void add2(const u32x3 va, const u32x3 vb)
-    {
-        auto both = [&](auto p_tag) {
-            constexpr int p = decltype(p_tag)::value;
-            const u16x2 ar = rgb24_pair<p, 0>(va), br = rgb24_pair<p, 0>(vb);
-            const u16x2 ag = rgb24_pair<p, 1>(va), bg = rgb24_pair<p, 1>(vb);
-            const u16x2 ab = rgb24_pair<p, 2>(va), bb = rgb24_pair<p, 2>(vb);
-#ifdef LFI_AB_NO_MINMAX3
-            lo[p][0] = __builtin_elementwise_min(__builtin_elementwise_min(lo[p][0], ar), br);
-            hi[p][0] = __builtin_elementwise_max(__builtin_elementwise_max(hi[p][0], ar), br);
-            lo[p][1] = __builtin_elementwise_min(__builtin_elementwise_min(lo[p][1], ag), bg);
-            hi[p][1] = __builtin_elementwise_max(__builtin_elementwise_max(hi[p][1], ag), bg);
-            lo[p][2] = __builtin_elementwise_min(__builtin_elementwise_min(lo[p][2], ab), bb);
-            hi[p][2] = __builtin_elementwise_max(__builtin_elementwise_max(hi[p][2], ab), bb);
-#else
-            lo[p][0] = min3_bytes(lo[p][0], ar, br);
-            hi[p][0] = max3_bytes(hi[p][0], ar, br);
-            lo[p][1] = min3_bytes(lo[p][1], ag, bg);
-            hi[p][1] = max3_bytes(hi[p][1], ag, bg);
-            lo[p][2] = min3_bytes(lo[p][2], ab, bb);
-            hi[p][2] = max3_bytes(hi[p][2], ab, bb);
-#endif
-        };
-        both(std::integral_constant<int, 0>{});
-        both(std::integral_constant<int, 1>{});
-    }
     // four u16: 16·range + (FLT_MIN tap ? 1 : 0), see focus_map.hpp
     __device__ __forceinline__ u32x2 encode() const
     {
@@ -472,8 +421,8 @@ __global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const Foc
     const int qx_wave = tx * 256 - a.radius_x; // extended column of lane 0's first pixel
     const focus_const_i64_ptr deltas = (focus_const_i64_ptr)(uintptr_t)(w.deltas + i0 * FOCUS_MAX_IDS);
     // wave-uniform base: the padded position of (qx_wave, qy) in slot 0; always ≥ one row / column inside the padding
-    const uint8_t *wave_base = w.pad + ((size_t)(qy + w.Py) * w.Wp + (size_t)(qx_wave + w.Px)) * FOCUS_PAD_BPP;
-    const uint32_t lane_off = 4u * FOCUS_PAD_BPP * lane;
+    const uint8_t *wave_base = reinterpret_cast<const uint8_t *>(w.pad) + ((size_t)(qy + w.Py) * w.Wp + (size_t)(qx_wave + w.Px)) * 4;
+    const uint32_t lane_off = 16u * lane;
 
     RangeAcc4 acc[CPW];
 #pragma unroll
@@ -488,10 +437,10 @@ __global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const Foc
         for(int c = 0; c < CPW; c++)
             d[c] = deltas[c * FOCUS_MAX_IDS + k];
     };
-    auto load_samples = [&](const int64_t (&d)[CPW], u32x3 (&px)[CPW]) {
+    auto load_samples = [&](const int64_t (&d)[CPW], u32x4 (&px)[CPW]) {
 #pragma unroll
         for(int c = 0; c < CPW; c++)
-            px[c] = *reinterpret_cast<const u32x3_a1 *>(wave_base + d[c] + lane_off);
+            px[c] = *reinterpret_cast<const u32x4_a4 *>(wave_base + d[c] + lane_off);
     };
     // No branches in the loop: past the last view the indices clamp to it — reducing a view twice changes no minimum or maximum —
     // so the compiler's vmcnt / lgkmcnt counts are exact (with conditional loads it has to assume they were not issued and waits
@@ -499,7 +448,7 @@ __global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const Foc
     // Round 3: two views per reduction (RangeAcc4::add2: min3 / max3), so the pipeline moves in PAIRS of views: the samples of pair
     // j + 1 are in flight while pair j is reduced, the deltas of pair j + 2 are on their way.
     int64_t dA[CPW], dB[CPW], dC[CPW], dD[CPW];
-    u32x3 pA[CPW], pB[CPW], pC[CPW], pD[CPW];
+    u32x4 pA[CPW], pB[CPW], pC[CPW], pD[CPW];
     const int last = n_ids - 1;
     load_deltas(0, dA);
     load_deltas(min(1, last), dB);
@@ -566,8 +515,8 @@ __device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const Focu
     const int n_ids = a.n_focus_ids;
     const int kk = lane < n_ids ? lane : 0;
     const float offy_l = a.offsets[a.focus_ids[kk]].y;
-    const uint8_t *pad = w.pad + 4u * FOCUS_PAD_BPP * lane;
-    const size_t tap_stride = (size_t)a.radius_y * w.Wp * FOCUS_PAD_BPP;
+    const uint8_t *pad = reinterpret_cast<const uint8_t *>(w.pad) + 16u * lane;
+    const size_t tap_stride = (size_t)a.radius_y * w.Wp * 4;
     for(uint32_t u = wave_id; u < uint32_t(a.height) * my_tiles * FOCUS_STEPS; u += n_waves)
     {
         // (row, tile of this XCD, candidate), candidate fastest: most units are unflagged and cost one uniform load
@@ -585,7 +534,7 @@ __device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const Focu
             // lane k: byte offset of view k's ty = 0 sample of this tile's first column
             const int sx_l = w.shifts[4 * (i * FOCUS_MAX_IDS + kk)];
             const int row_l = warp_float(y, f, offy_l) - a.radius_y + w.Py;
-            const uint64_t off_l = (((uint64_t)kk * w.Hp + row_l) * w.Wp + uint64_t(int(tile) * 256 - a.radius_x + w.Px + sx_l)) * uint64_t(FOCUS_PAD_BPP);
+            const uint64_t off_l = (((uint64_t)kk * w.Hp + row_l) * w.Wp + uint64_t(int(tile) * 256 - a.radius_x + w.Px + sx_l)) * 4u;
             // the taps (ty = t − 1) of this row that need their own line for this candidate: wave-uniform, usually just t = 2
             uint32_t tm = 0u;
 #pragma unroll
@@ -595,25 +544,25 @@ __device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const Focu
 #pragma unroll
             for(int t = 0; t < 3; t++)
                 acc[t].init();
-            u32x3 cur[3], nxt[3];
-            auto fetch = [&](const int k, u32x3 (&v)[3]) {
+            u32x4 cur[3], nxt[3];
+            auto fetch = [&](const int k, u32x4 (&v)[3]) {
                 const uint8_t *p = pad + readlane64(off_l, k);
 #pragma unroll
                 for(int t = 0; t < 3; t++)
                     if(tm & (1u << t)) // wave-uniform
-                        v[t] = *reinterpret_cast<const u32x3_a1 *>(p + t * tap_stride);
+                        v[t] = *reinterpret_cast<const u32x4_a4 *>(p + t * tap_stride);
                     else
-                        v[t] = u32x3{0u, 0u, 0u};
+                        v[t] = u32x4{0u, 0u, 0u, 0u};
             };
             // two views per reduction (min3 / max3); past the last view the index clamps to it (reducing a view twice changes nothing)
-            auto reduce2 = [&](const u32x3 (&va)[3], const u32x3 (&vb)[3]) {
+            auto reduce2 = [&](const u32x4 (&va)[3], const u32x4 (&vb)[3]) {
 #pragma unroll
                 for(int t = 0; t < 3; t++)
                     if(tm & (1u << t))
                         acc[t].add2(va[t], vb[t]);
             };
             const int last = n_ids - 1;
-            u32x3 cur2[3], nxt2[3];
+            u32x4 cur2[3], nxt2[3];
             fetch(0, cur);
             fetch(min(1, last), nxt);
             int k = 0;
@@ -662,9 +611,9 @@ __device__ __forceinline__ void focus_lines_cols(const KernelArgs &a, const Focu
     const int n_ids = a.n_focus_ids;
     const int kk = lane < n_ids ? lane : 0;
     const float offx_l = a.offsets[a.focus_ids[kk]].x;
-    const uint8_t *pad = w.pad;
+    const uint8_t *pad = reinterpret_cast<const uint8_t *>(w.pad);
     const int rx = a.radius_x;
-    const size_t row_bytes = (size_t)w.Wp * FOCUS_PAD_BPP;
+    const size_t row_bytes = (size_t)w.Wp * 4;
     for(uint32_t u = wave_id; u < (rb1 - rb0) * chunks; u += n_waves)
     {
         const uint32_t rb = rb0 + u / chunks, chunk = u % chunks;
@@ -697,7 +646,7 @@ __device__ __forceinline__ void focus_lines_cols(const KernelArgs &a, const Focu
         uint32_t cur[R][3], nxt[R][3];
         auto fetch = [&](const int k, uint32_t (&v)[R][3]) {
             const float offx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(uint32_t, offx_l), k));
-            const uint32_t left = uint32_t(warp_float(x, f, offx) - rx + w.Px) * uint32_t(FOCUS_PAD_BPP); // tx = 0 sample column, bytes
+            const uint32_t left = uint32_t(warp_float(x, f, offx) - rx + w.Px) * 4u; // tx = 0 sample column, bytes
             const uint8_t *row = pad + readlane64(off_l, k);
 #pragma unroll
             for(int t = 0; t < 3; t++)
@@ -705,7 +654,7 @@ __device__ __forceinline__ void focus_lines_cols(const KernelArgs &a, const Focu
                 const bool want = (tm >> t) & 1u;
 #pragma unroll
                 for(int r = 0; r < R; r++)
-                    v[r][t] = want ? *reinterpret_cast<const u32_a1 *>(row + r * row_bytes + uint32_t(t * rx) * uint32_t(FOCUS_PAD_BPP) + left) : 0u; // R G B + one byte RangeAcc1 ignores
+                    v[r][t] = want ? *reinterpret_cast<const uint32_t *>(row + r * row_bytes + uint32_t(t * rx) * 4u + left) : 0u;
             }
         };
         auto reduce2 = [&](const uint32_t (&va)[R][3], const uint32_t (&vb)[R][3]) { // two views per reduction (min3 / max3)
@@ -759,18 +708,18 @@ __device__ __forceinline__ uint32_t focus_exact_taps(const KernelArgs &a, const 
     const float f = focus_candidate(a, i);
     const focus_const_float_ptr c_offsets = (focus_const_float_ptr)(uintptr_t)a.offsets;
     const focus_const_int_ptr c_ids = (focus_const_int_ptr)(uintptr_t)a.focus_ids;
-    const size_t plane_bytes = (size_t)w.Wp * w.Hp * FOCUS_PAD_BPP;
+    const size_t plane_bytes = (size_t)w.Wp * w.Hp * 4;
     RangeAcc1 acc[9];
 #pragma unroll
     for(int t = 0; t < 9; t++)
         acc[t].init();
-    const uint8_t *pad = w.pad;
+    const uint8_t *pad = reinterpret_cast<const uint8_t *>(w.pad);
     // top-left tap of view k; all nine taps are at non-negative, wave-uniform byte offsets from it
     auto corner_of = [&](const int k) {
         const int g = c_ids[k];
         const float offx = c_offsets[2 * g], offy = c_offsets[2 * g + 1];
         const int cx = warp_float(x, f, offx), cy = warp_float(y, f, offy);
-        return pad + (size_t)k * plane_bytes + uint32_t((cy - ry + w.Py) * w.Wp + (cx - rx + w.Px)) * uint32_t(FOCUS_PAD_BPP);
+        return pad + (size_t)k * plane_bytes + uint32_t((cy - ry + w.Py) * w.Wp + (cx - rx + w.Px)) * 4u;
     };
     const int last = a.n_focus_ids - 1;
     for(int k = 0; k <= last; k += 2) // two views per reduction (min3 / max3); an odd tail repeats the last view
@@ -781,10 +730,10 @@ __device__ __forceinline__ uint32_t focus_exact_taps(const KernelArgs &a, const 
 #pragma unroll
             for(int tx = 0; tx < 3; tx++)
             {
-                const uint32_t tap = uint32_t(ty * ry * w.Wp + tx * rx) * uint32_t(FOCUS_PAD_BPP);
+                const uint32_t tap = uint32_t(ty * ry * w.Wp + tx * rx) * 4u;
                 const bool want = (m9 >> (tx * 3 + ty)) & 1u;
-                const uint32_t pa = want ? *reinterpret_cast<const u32_a1 *>(ca + tap) : 0u;
-                const uint32_t pb = want ? *reinterpret_cast<const u32_a1 *>(cb + tap) : 0u;
+                const uint32_t pa = want ? *reinterpret_cast<const uint32_t *>(ca + tap) : 0u;
+                const uint32_t pb = want ? *reinterpret_cast<const uint32_t *>(cb + tap) : 0u;
                 acc[tx * 3 + ty].add2(pa, pb);
             }
     }

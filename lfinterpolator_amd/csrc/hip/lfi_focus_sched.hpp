@@ -46,7 +46,7 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     w.Py = Sy + ry;
     w.Wp = (w.Px + std::max(W + Sx + rx, w.We_p - rx + Sx) + 3) / 4 * 4;
     w.Hp = w.Py + std::max(H + Sy + ry, w.He_p - ry + Sy);
-    const size_t pad_bytes = (size_t)lfi::FOCUS_PAD_BPP * (size_t)ctx->n_focus_ids * w.Hp * w.Wp + 4; // + 4: a one-pixel load reads a whole dword
+    const size_t pad_bytes = sizeof(uint32_t) * (size_t)ctx->n_focus_ids * w.Hp * w.Wp;
     if(pad_bytes > ((size_t)16 << 30))
         return LFI_OK;
     size_t at = 0;
@@ -100,7 +100,7 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     w.E = reinterpret_cast<uint16_t *>(base + o_E);
     w.K = reinterpret_cast<uint16_t *>(base + o_K);
     w.deltas = reinterpret_cast<int64_t *>(base + o_deltas);
-    w.pad = base + o_pad;
+    w.pad = reinterpret_cast<uint32_t *>(base + o_pad);
     // Two streams: the plan and the flagged-pair passes are small, latency-bound kernels; they run beside the padded copy
     // and the range pass (bandwidth / VALU bound) instead of in front of them.
     //   main:  plan_shifts ─┬─ pad ─┬─ range ──────────────────────────┬──────────────┬─ pick (→ filter, by the caller)
