@@ -1,13 +1,13 @@
-# rocprofv3 --kernel-trace --stats per BASELINE configuration (round 3): the kernel-stats CSVs that back bench.py's `also` table.
-# Copies <name>_kernel_stats.csv into gpurun_out/prof_r03/; commit them under profiles/ as r03_<name>_kernel_stats.csv.
+# rocprofv3 --kernel-trace --stats per BASELINE configuration (ROUND=r04 by default): the kernel-stats CSVs that back bench.py's `also` table.
+# Copies <name>_kernel_stats.csv into gpurun_out/prof_${ROUND:-r04}/; commit them under profiles/ as <round>_<name>_kernel_stats.csv.
 : ${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/prof_r03
+mkdir -p gpurun_out/prof_${ROUND:-r04}
 run() { # name, command...
   name=$1; shift
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r03/$name -o p -- "$@" > gpurun_out/prof_r03/$name.log 2>&1 || echo "$name failed"
-  f=$(find gpurun_out/prof_r03/$name -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && cp "$f" gpurun_out/prof_r03/${name}_kernel_stats.csv
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${ROUND:-r04}/$name -o p -- "$@" > gpurun_out/prof_${ROUND:-r04}/$name.log 2>&1 || echo "$name failed"
+  f=$(find gpurun_out/prof_${ROUND:-r04}/$name -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" gpurun_out/prof_${ROUND:-r04}/${name}_kernel_stats.csv
 }
 run bench_planar python3 bench.py --no-cpu-baseline --no-also --steps 50 --warmup 5
 run bench_rgba python3 bench.py --no-cpu-baseline --no-also --steps 50 --warmup 5 --layout rgba
@@ -17,4 +17,7 @@ run config5_fixed python3 tools/run_p3.py 5 planar 10
 run config5_focus_map python3 tools/run_focus.py auto 15 3840 2160 scene
 run config2_focus_map python3 tools/run_focus.py auto 8 1920 1080 scene
 run also_table python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 --also-iters 6
-head -40 gpurun_out/prof_r03/config5_focus_map_kernel_stats.csv
+run config5_allfocus_ten python3 tools/run_allfocus.py TEN_WM 6 estimated
+run config5_allfocus_std python3 tools/run_allfocus.py STD 6 estimated
+run config5_allfocus_std_once python3 tools/run_allfocus.py STD 6 estimated filtered_gather_once
+python3 bench.py --no-cpu-baseline --no-also --steps 50 --warmup 5 > /dev/null 2>&1; head -12 gpurun_out/prof_${ROUND:-r04}/bench_planar_kernel_stats.csv
