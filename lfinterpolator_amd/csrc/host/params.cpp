@@ -88,9 +88,11 @@ lfi_params HostParams::abi() const
     return p;
 }
 
+// The point half way along the trajectory, start + (end − start)·0.5 per coordinate (what reference src/interpolator.cu:189-192 computes)
 Vec2 trajectoryCenter(Vec4 startEndPoints)
 {
-    return startEndPoints.xy() + (startEndPoints.zw() - startEndPoints.xy()) * 0.5f;
+    const float dCol = startEndPoints.z - startEndPoints.x, dRow = startEndPoints.w - startEndPoints.y;
+    return {startEndPoints.x + dCol * 0.5f, startEndPoints.y + dRow * 0.5f};
 }
 
 // reference src/interpolator.cu:318-337; unlike the reference, a malformed string is an error instead of
@@ -123,92 +125,110 @@ Vec4 Parameterizer::interpretTrajectory(const std::string &trajectory) const
     return absolute;
 }
 
-// reference src/interpolator.cu:174-182 with the view count as a parameter (64 there)
+namespace {
+
+// Euclidean distance as glm::distance rounds it: the squares and their sum in float, then sqrtf
+inline float gridDistance(float colA, float rowA, float colB, float rowB)
+{
+    const float dc = colB - colA, dr = rowB - rowA;
+    return std::sqrt(dc * dc + dr * dr);
+}
+
+} // namespace
+
+// Camera i of `views` equally spaced cameras from the trajectory's start to its end (a single view sits on the start point).  The step is
+// (end − start) / (views − 1), the camera start + step·i — the reference's rounding (src/interpolator.cu:174-182; 64 views there).
 std::vector<Vec2> Parameterizer::generateTrajectory(Vec4 startEndPoints, int views) const
 {
-    std::vector<Vec2> trajectory;
-    trajectory.reserve(views);
+    std::vector<Vec2> cameras(static_cast<size_t>(std::max(views, 1)), Vec2{startEndPoints.x, startEndPoints.y});
     if(views <= 1)
-    {
-        trajectory.push_back(startEndPoints.xy());
-        return trajectory;
-    }
-    const Vec2 step = (startEndPoints.zw() - startEndPoints.xy()) / static_cast<float>(views - 1);
+        return cameras;
+    const float last = static_cast<float>(views - 1);
+    const float stepCol = (startEndPoints.z - startEndPoints.x) / last, stepRow = (startEndPoints.w - startEndPoints.y) / last;
     for(int i = 0; i < views; i++)
-        trajectory.push_back(startEndPoints.xy() + step * static_cast<float>(i));
-    return trajectory;
+    {
+        const float fi = static_cast<float>(i);
+        cameras[i] = {startEndPoints.x + stepCol * fi, startEndPoints.y + stepRow * fi};
+    }
+    return cameras;
 }
 
-// reference src/interpolator.cu:156-172
+// One view's blending weights, image g = col·rows + row: (dmax − distance(camera, image))^effect, normalised by their sum accumulated in
+// image order — float powf, float running sum, one division per weight (src/interpolator.cu:156-172)
 std::vector<float> Parameterizer::generateWeights(Vec2 coords, float effect) const
 {
-    const float maxDistance = distance(Vec2{0, 0}, toVec2(colsRows));
-    float weightSum = 0;
-    std::vector<float> weightVals;
-    weightVals.reserve(static_cast<size_t>(colsRows.x) * colsRows.y);
-    for(int col = 0; col < colsRows.x; col++)
-        for(int row = 0; row < colsRows.y; row++)
-        {
-            float weight = maxDistance - distance(coords, Vec2{static_cast<float>(col), static_cast<float>(row)});
-            weight = powf(weight, effect);
-            weightSum += weight;
-            weightVals.push_back(weight);
-        }
-    for(auto &weight : weightVals)
-        weight /= weightSum;
-    return weightVals;
+    const int cols = colsRows.x, rows = colsRows.y;
+    const float dmax = gridDistance(0.0f, 0.0f, static_cast<float>(cols), static_cast<float>(rows));
+    std::vector<float> w(static_cast<size_t>(cols) * rows);
+    float total = 0.0f;
+    for(size_t g = 0; g < w.size(); g++)
+    {
+        const float col = static_cast<float>(g / rows), row = static_cast<float>(g % rows);
+        const float closeness = dmax - gridDistance(coords.x, coords.y, col, row);
+        w[g] = powf(closeness, effect);
+        total += w[g];
+    }
+    for(float &value : w)
+        value /= total;
+    return w;
 }
 
-// reference src/interpolator.cu:209-224 (the host half: the upload is lfi_set_params)
+// [views][N] fp16 bit patterns, rounded to nearest even like static_cast<half>(float) on the host (src/interpolator.cu:209-224; the upload
+// is lfi_set_params)
 std::vector<uint16_t> Parameterizer::weightMatrix(Vec4 startEndPoints, float effect, int views) const
 {
-    std::vector<uint16_t> matrix;
-    matrix.reserve(static_cast<size_t>(views) * colsRows.x * colsRows.y);
-    for(const auto &view : generateTrajectory(startEndPoints, views))
-        for(float w : generateWeights(view, effect))
-            matrix.push_back(floatToHalfBits(w));
+    const size_t n = static_cast<size_t>(colsRows.x) * colsRows.y;
+    const std::vector<Vec2> cameras = generateTrajectory(startEndPoints, views);
+    std::vector<uint16_t> matrix(cameras.size() * n);
+    for(size_t v = 0; v < cameras.size(); v++)
+    {
+        const std::vector<float> row = generateWeights(cameras[v], effect);
+        std::transform(row.begin(), row.end(), matrix.begin() + v * n, floatToHalfBits);
+    }
     return matrix;
 }
 
-// reference src/interpolator.cu:226-246
+// Per image: the shift of the image against the trajectory's centre at focus 1, in pixels — ((centre − position) / grid) · resolution,
+// the row component also times (width / height) / aspect — and the same times `focus`, rounded half away from zero, for the fixed-focus
+// kernels (src/interpolator.cu:226-246)
 void Parameterizer::offsets(float aspect, float focus, Vec4 startEndPoints, std::vector<lfi_float2> &outOffsets,
                             std::vector<lfi_int2> &outFocused) const
 {
-    outOffsets.clear();
-    outFocused.clear();
-    const Vec2 center = trajectoryCenter(startEndPoints);
-    const float offsetAspect = (static_cast<float>(resolution.x) / resolution.y) / aspect;
-    const Vec2 res{static_cast<float>(resolution.x), static_cast<float>(resolution.y)};
-    for(int col = 0; col < colsRows.x; col++)
-        for(int row = 0; row < colsRows.y; row++)
-        {
-            const Vec2 position{static_cast<float>(col), static_cast<float>(row)};
-            Vec2 offset = (center - position) / toVec2(colsRows);
-            offset = offset * res;
-            offset.y *= offsetAspect;
-            outOffsets.push_back({offset.x, offset.y});
-            const IVec2 rounded = roundToInt(offset * Vec2{focus, focus});
-            outFocused.push_back({rounded.x, rounded.y});
-        }
+    const int cols = colsRows.x, rows = colsRows.y;
+    const size_t n = static_cast<size_t>(cols) * rows;
+    outOffsets.assign(n, lfi_float2{0.0f, 0.0f});
+    outFocused.assign(n, lfi_int2{0, 0});
+    const Vec2 centre = trajectoryCenter(startEndPoints);
+    const float width = static_cast<float>(resolution.x), height = static_cast<float>(resolution.y);
+    const float rowScale = (static_cast<float>(resolution.x) / resolution.y) / aspect;
+    for(size_t g = 0; g < n; g++)
+    {
+        const float col = static_cast<float>(g / rows), row = static_cast<float>(g % rows);
+        const float shiftX = ((centre.x - col) / static_cast<float>(cols)) * width;
+        const float shiftY = (((centre.y - row) / static_cast<float>(rows)) * height) * rowScale;
+        outOffsets[g] = {shiftX, shiftY};
+        outFocused[g] = {static_cast<int>(std::round(shiftX * focus)), static_cast<int>(std::round(shiftY * focus))};
+    }
 }
 
 // reference src/interpolator.cu:194-207; at most 32 ids (the reference indexes 32 unconditionally: SURVEY.md D4) and ties
 // ordered by id (std::sort leaves them unspecified there)
 std::vector<int32_t> Parameterizer::selectFocusMapViews(Vec4 startEndPoints) const
 {
-    std::vector<std::pair<float, int32_t>> distances;
-    const Vec2 center = trajectoryCenter(startEndPoints);
-    for(int col = 0; col < colsRows.x; col++)
-        for(int row = 0; row < colsRows.y; row++)
-            distances.push_back({distance(Vec2{static_cast<float>(col), static_cast<float>(row)}, center),
-                                 static_cast<int32_t>(distances.size())});
-    std::stable_sort(distances.begin(), distances.end(),
-                     [](const auto &a, const auto &b) { return a.first < b.first; });
-    std::vector<int32_t> ids;
-    const size_t count = std::min<size_t>(LFI_MAX_FOCUS_IDS, distances.size());
-    for(size_t i = 0; i < count; i++)
-        ids.push_back(distances[i].second);
-    return ids;
+    const int rows = colsRows.y;
+    const size_t n = static_cast<size_t>(colsRows.x) * rows;
+    const Vec2 centre = trajectoryCenter(startEndPoints);
+    std::vector<float> dist(n);
+    std::vector<int32_t> order(n);
+    for(size_t g = 0; g < n; g++)
+    {
+        dist[g] = gridDistance(static_cast<float>(g / rows), static_cast<float>(g % rows), centre.x, centre.y);
+        order[g] = static_cast<int32_t>(g);
+    }
+    // nearest first; images at the same distance in id order
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return dist[a] < dist[b]; });
+    order.resize(std::min<size_t>(LFI_MAX_FOCUS_IDS, n));
+    return order;
 }
 
 // reference src/interpolator.cu:139-146; a zero radius (image narrower than 100 px) never advances the tap loops of the
