@@ -10,6 +10,11 @@ cols = rows = 15; W, H, V = 3840, 2160, 64
 ctx = L.Context(0); ctx.set_grid(cols, rows, W, H)
 ctx.set_params(L.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.22, 0.17, 7.0, 1.783, V))
 ctx.fill_synthetic_scene(0x1F1F)
+import os
+if os.environ.get("LFI_TEN_VARIANT"):
+    ctx.set_variant("TEN_WM", os.environ["LFI_TEN_VARIANT"])
+if os.environ.get("LFI_STD_VARIANT"):
+    ctx.set_variant("STD", os.environ["LFI_STD_VARIANT"])
 def t(method, n=6):
     for _ in range(3): ctx.render(method, all_focus=True)
     ctx.sync()
