@@ -74,6 +74,34 @@ def fuzz_blend(L, oc, n_cases: int, seed: int, log=None) -> list:
         d = int(np.abs(got.astype(int) - want_ten.astype(int)).max())
         if d > TEN_TOL_LSB or not (got == want_rgba).all() or not (part == got).all() or not (ctx.download_views() == want_std).all():
             bad.append(dict(case, what="planar layout", kernel=kernel, lsb=d, v0=v0, v1=v1))
+        # round 4: the quilt of a random tiling (assembled on the device, filled in two parts) is the montage of the views; and after
+        # lfi_release_inputs — the planar copy is the only copy of the inputs — STD stays the oracle's and TEN_WM the same bytes
+        ctx.render("TEN_WM")
+        ctx.sync()
+        tx = int(rng.integers(1, 5))
+        ty = int(rng.integers(1, max(2, min(4, V // tx) + 1)))
+        if tx * ty <= V:
+            quilt = np.zeros((ty * H, tx * W, 4), np.uint8)
+            cut = int(rng.integers(0, tx * ty + 1))
+            if cut > 0:
+                ctx.download_quilt_tiles(quilt, tx, ty, 0, cut)
+            if cut < tx * ty:
+                ctx.download_quilt_tiles(quilt, tx, ty, cut, tx * ty - cut, v0=cut)
+            montage = got[:tx * ty].reshape(ty, tx, H, W, 4).transpose(0, 2, 1, 3, 4).reshape(ty * H, tx * W, 4)
+            if not (quilt == montage).all():
+                bad.append(dict(case, what="quilt", tiles=(tx, ty), cut=cut))
+        try:
+            ctx.release_inputs()
+            ctx.render("TEN_WM")
+            ctx.sync()
+            same = bool((ctx.download_views() == got).all())
+            ctx.render("STD")
+            ctx.sync()
+            if not same or not (ctx.download_views() == want_std).all():
+                bad.append(dict(case, what="released inputs", ten_same=same))
+        except L.LfiError as e:
+            if "cannot be built" not in str(e):          # (absurd offsets: the planar copy is refused, and so is the release)
+                bad.append(dict(case, what="released inputs", error=str(e)))
         ctx.close()
         if log and (i + 1) % 20 == 0:
             log(f"{i + 1} cases, {len(bad)} mismatches")
@@ -164,6 +192,14 @@ def fuzz_allfocus(L, oc, n_cases: int, seed: int, log=None) -> list:
             d = int(np.abs(ctx.download_views().astype(int) - want_ten.astype(int)).max())
             if not ok_std or d > TEN_TOL_LSB:
                 bad.append(dict(case, what="all-focus", layout=layout, std_exact=ok_std, lsb=d, kernel=ctx.last_kernel_name()))
+            if cols * rows > 128 and layout == "rgba":
+                # three or four chunks of images: blend_afs (every sample gathered once; round 4) must give the same bytes
+                ctx.set_variant("STD", "filtered_gather_once")
+                ctx.render("STD", all_focus=True)
+                ctx.sync()
+                if ctx.last_kernel_name() != "blend_afs<STD,allfocus>" or not (ctx.download_views() == want_std).all():
+                    bad.append(dict(case, what="all-focus", layout=layout, std_exact=False, kernel=ctx.last_kernel_name()))
+                ctx.set_variant("STD", "auto")
         ctx.close()
         if log and (i + 1) % 20 == 0:
             log(f"{i + 1} cases, {len(bad)} mismatches")
