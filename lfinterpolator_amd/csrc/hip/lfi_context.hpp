@@ -41,6 +41,10 @@ struct lfi_ctx
     // side stream of the factored focus-map estimate (its small passes overlap the large ones), created on first use
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_pad = nullptr, ev_join = nullptr, ev_range = nullptr;
+    // the focus map's filter (map 0 → map 1) runs on the side stream behind the pick: an all-focus TEN_WM render, which reads map 0
+    // (src/kernels.cu:430), does not wait for it; whatever reads map 1 or writes either map joins it first (join_filter)
+    hipEvent_t ev_pick = nullptr, ev_filter = nullptr;
+    bool filter_pending = false;
     int cols = 0, rows = 0, n = 0, width = 0, height = 0;
     // row window (lfi_set_row_window): input rows held / output rows rendered; the whole image by default
     int in_y0 = 0, in_rows = 0, out_y0 = 0, out_rows = 0;
@@ -186,6 +190,16 @@ int join_uploads(lfi_ctx *c)
     LFI_HIP(c, hipEventRecord(c->ev_uploads, c->copy_stream));
     LFI_HIP(c, hipStreamWaitEvent(c->stream, c->ev_uploads, 0));
     c->uploads_pending = false;
+    return LFI_OK;
+}
+
+// Order everything enqueued on the compute stream from now on after the focus-map filter that may still run on the side stream.
+int join_filter(lfi_ctx *c)
+{
+    if(!c->filter_pending)
+        return LFI_OK;
+    LFI_HIP(c, hipStreamWaitEvent(c->stream, c->ev_filter, 0));
+    c->filter_pending = false;
     return LFI_OK;
 }
 
@@ -359,7 +373,12 @@ void touch_images(lfi_ctx *c, int g0, int g1)
 
 bool image_changed_since(const lfi_ctx *c, int g, uint64_t version)
 {
-    return c->grid_full_version > version || (int)c->img_version.size() != c->n || c->img_version[g] > version;
+    // no per-image record (nothing but whole-grid changes so far: touch_images starts the record and bumps grid_full_version when it does):
+    // the whole-grid version decides.  (Round 3 answered "changed" here, and contexts filled only by whole-grid calls — lfi_fill_synthetic_scene,
+    // an attached grid + lfi_grid_modified — re-padded all sampled images on EVERY lfi_focus_map, one launch per image: 0.5 ms at 4K.)
+    if((int)c->img_version.size() != c->n)
+        return c->grid_full_version > version;
+    return c->grid_full_version > version || c->img_version[g] > version;
 }
 
 void free_params(lfi_ctx *c)

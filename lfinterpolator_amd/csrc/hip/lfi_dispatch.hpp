@@ -564,6 +564,9 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
 {
     if(int rc = join_uploads(c))
         return rc;
+    if(all_focus && a_in.map_index == 1)
+        if(int rc = join_filter(c)) // the filtered map may still be in the making on the side stream
+            return rc;
     if(c->inputs_released && !(wants_derived_copy(c, method, all_focus, a_in) && ensure_planar(c)))
         return fail(c, LFI_EINVAL, "the RGBA inputs were released (lfi_release_inputs): only fixed-focus renders whose offsets the planar copy was built for "
                                    "are served (no all-focus render, debug mode, weights outside [0, 2) or larger offsets) - upload the images again");

@@ -75,6 +75,9 @@ int lfi_destroy(lfi_ctx *ctx)
         return LFI_EINVAL;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if(ctx->aux_stream)
+        (void)hipStreamSynchronize(ctx->aux_stream); // a focus-map filter may still run there
+    ctx->filter_pending = false;
     free_params(ctx);
     free_param_staging(ctx);
     free_views(ctx);
@@ -113,6 +116,10 @@ int lfi_destroy(lfi_ctx *ctx)
         (void)hipEventDestroy(ctx->ev_join);
     if(ctx->ev_range)
         (void)hipEventDestroy(ctx->ev_range);
+    if(ctx->ev_pick)
+        (void)hipEventDestroy(ctx->ev_pick);
+    if(ctx->ev_filter)
+        (void)hipEventDestroy(ctx->ev_filter);
     if(ctx->aux_stream)
         (void)hipStreamDestroy(ctx->aux_stream);
     if(ctx->own_stream)
@@ -132,6 +139,8 @@ int lfi_set_stream(lfi_ctx *ctx, void *hip_stream)
     // input planes (lfi_fill_synthetic, uploads), the derived planar copy (planar_build), the focus maps and workspace, the views.
     // Everything enqueued so far is ordered before everything enqueued from now on, without blocking the host.
     if(int rc = bind(ctx))
+        return rc;
+    if(int rc = join_filter(ctx))
         return rc;
     LFI_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
     LFI_HIP(ctx, hipStreamWaitEvent(next, ctx->ev_order, 0));
@@ -154,6 +163,8 @@ int lfi_set_grid(lfi_ctx *ctx, int cols, int rows, int width, int height)
     if(int rc = bind(ctx))
         return rc;
     if(int rc = lfi_upload_wait(ctx))
+        return rc;
+    if(int rc = join_filter(ctx))
         return rc;
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_params(ctx);
@@ -738,6 +749,8 @@ int lfi_focus_map(lfi_ctx *ctx)
         return rc;
     if(int rc = join_uploads(ctx))
         return rc;
+    if(int rc = join_filter(ctx)) // the previous map's filter still reads map 0, which this call rewrites
+        return rc;
     KernelArgs a = make_args(ctx, 0, ctx->views_n, LFI_METHOD_STD);
     if(ctx->windowed)
     {
@@ -780,6 +793,24 @@ int lfi_focus_map(lfi_ctx *ctx)
     else // "packed_p2" (also the fallback of "lds" for very large radii)
         hipLaunchKernelGGL((lfi::focus_estimate_packed<2, 4>), dim3((ctx->width + 127) / 128, ctx->height), dim3(64), 0, ctx->stream, a);
     LFI_HIP(ctx, hipGetLastError());
+    if(done && ctx->aux_stream)
+    {
+        // map 1 = the box mean of map 0 (FocusMap::filter, src/kernels.cu:260-280), on the side stream: the reference's Tensors::process<true>
+        // reads map 0 (src/kernels.cu:430), so a TEN_WM all-focus render enqueued next runs BESIDE the filter (0.13 ms at 4K) instead of
+        // behind it; everything that reads map 1 or writes a map joins the side stream first (join_filter)
+        if(!ctx->ev_pick)
+        {
+            LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pick, hipEventDisableTiming));
+            LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_filter, hipEventDisableTiming));
+        }
+        LFI_HIP(ctx, hipEventRecord(ctx->ev_pick, ctx->stream));
+        LFI_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_pick, 0));
+        hipLaunchKernelGGL(lfi::focus_filter, pixel_grid(ctx), dim3(256), 0, ctx->aux_stream, a);
+        LFI_HIP(ctx, hipGetLastError());
+        LFI_HIP(ctx, hipEventRecord(ctx->ev_filter, ctx->aux_stream));
+        ctx->filter_pending = true;
+        return LFI_OK;
+    }
     hipLaunchKernelGGL(lfi::focus_filter, pixel_grid(ctx), dim3(256), 0, ctx->stream, a);
     LFI_HIP(ctx, hipGetLastError());
     return LFI_OK;
@@ -992,6 +1023,8 @@ int lfi_sync(lfi_ctx *ctx)
         return rc;
     if(int rc = join_uploads(ctx))
         return rc;
+    if(int rc = join_filter(ctx))
+        return rc;
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LFI_OK;
 }
@@ -1011,6 +1044,8 @@ int lfi_timer_stop(lfi_ctx *ctx, float *out_ms)
     if(!ctx || !out_ms)
         return LFI_EINVAL;
     if(int rc = bind(ctx))
+        return rc;
+    if(int rc = join_filter(ctx)) // a timed region ends when ALL its work has: the side stream's filter included
         return rc;
     LFI_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     LFI_HIP(ctx, hipEventSynchronize(ctx->ev1));
@@ -1095,6 +1130,8 @@ int lfi_download_map(lfi_ctx *ctx, int k, uint8_t *rgba, size_t pitch_bytes)
     if(k < 0 || k > 1 || !rgba || pitch_bytes < (size_t)ctx->width * 4)
         return fail(ctx, LFI_EINVAL, "bad map index, pointer or pitch");
     if(int rc = bind(ctx))
+        return rc;
+    if(int rc = join_filter(ctx))
         return rc;
     LFI_HIP(ctx, hipMemcpy2DAsync(rgba, pitch_bytes, ctx->maps + plane_bytes(ctx) * k, (size_t)ctx->width * 4,
                                   (size_t)ctx->width * 4, ctx->height, hipMemcpyDeviceToHost, ctx->stream));
@@ -1215,6 +1252,8 @@ int lfi_upload_map(lfi_ctx *ctx, int k, const uint8_t *rgba, size_t pitch_bytes)
         return fail(ctx, LFI_EINVAL, "bad map index, pointer or pitch");
     if(int rc = bind(ctx))
         return rc;
+    if(int rc = join_filter(ctx))
+        return rc;
     LFI_HIP(ctx, hipMemcpy2DAsync(ctx->maps + plane_bytes(ctx) * k, (size_t)ctx->width * 4, rgba, pitch_bytes,
                                   (size_t)ctx->width * 4, ctx->height, hipMemcpyHostToDevice, ctx->stream));
     LFI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1309,6 +1348,8 @@ int lfi_download_coords(lfi_ctx *ctx, int g, int all_focus, int map_index, lfi_i
     lfi_int2 *d = nullptr;
     LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), bytes));
     KernelArgs a = make_args(ctx, 0, ctx->views_n, LFI_METHOD_STD);
+    if(int rc = join_filter(ctx))
+        return rc;
     a.map_index = map_index;
     hipLaunchKernelGGL(lfi::dump_coords, pixel_grid(ctx), dim3(256), 0, ctx->stream, a, g, all_focus, d);
     hipError_t e = hipGetLastError();
