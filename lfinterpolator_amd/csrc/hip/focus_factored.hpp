@@ -34,7 +34,6 @@
 // focus_pick (map 0) → focus_filter (map 1).
 #pragma once
 
-#include "blend_ten_persist.hpp" // dma16_s
 #include "focus_map.hpp"
 
 namespace lfi {
@@ -489,147 +488,6 @@ __global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const Foc
     {
         uint16_t *dst = w.E + ((size_t)(i0 + c) * w.He_p + ey) * w.We_p + tx * 256 + 4 * lane;
         *reinterpret_cast<u32x2 *>(dst) = acc[c].encode();
-    }
-}
-
-// E_i(q) with the views' samples staged through LDS (round 4).  focus_range is bound by L1 tag accesses — a 1-KB wave-load at pixel alignment
-// costs 24, one per CU and cycle for 94 % of the kernel (profiles/r03_pmc_focus_range_summary.txt) — and every (row, candidate) pair of a tile
-// loads its own 256 pixels of a view although the pairs' source windows overlap almost completely: the four candidates of a group differ by a
-// few pixels and rows of shift.  Here a workgroup takes 256 extended columns × 8 extended rows (two rows per wave) of four consecutive
-// candidates and, per view, brings ONE patch of 16 rows × 272 pixels into LDS (17 LDS-DMA wave-loads) that serves all 32 (row, candidate)
-// pairs — 1.9× fewer bytes through the L1 than 32 wave-loads; the pairs then read LDS (conflict-free: a lane owns the pixels lane, 64 + lane,
-// 128 + lane, 192 + lane of its rows, so that every ds_read_b32 covers 64 consecutive dwords).  Two views per step, as the min3 / max3
-// reduction wants them.  Single-buffered: three workgroups per CU cover each other's fetch latency.  Preconditions (checked on the host,
-// launch_focus_factored: else focus_range): within a group of four candidates a view's shifts differ by at most 16 pixels and 8 rows, and the
-// padded planes end with 16 rows + 64 bytes of slack (a patch is always fetched whole).
-constexpr int FRL_ROWS = 8;                      // extended rows per tile
-constexpr int FRL_PATCH_ROWS = 16, FRL_PATCH_W = 272; // rows × pixels of a view's patch
-constexpr int FRL_PATCH_B = FRL_PATCH_ROWS * FRL_PATCH_W * 4; // 17,408 bytes = 17 wave-loads of 1 KB
-constexpr int FRL_MAX_DX = FRL_PATCH_W - 256, FRL_MAX_DY = FRL_PATCH_ROWS - FRL_ROWS;
-
-__global__ void __launch_bounds__(256, 3) focus_range_lds(const KernelArgs a, const FocusWork w, const uint32_t nblocks, const int striped)
-{
-    constexpr int CPW = 4, GROUPS = FOCUS_STEPS / CPW, PIECES = FRL_PATCH_B / 1024;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * FRL_PATCH_B / 4];
-    const uint32_t tiles_x = uint32_t(w.We_p) >> 8, tiles_y = (uint32_t(w.He_p) + FRL_ROWS - 1) / FRL_ROWS;
-    uint32_t tx, ty, group;
-    if(striped)
-    {
-        if(!stripe_map(blockIdx.x, tiles_x, tiles_y, GROUPS, tx, ty, group))
-            return;
-    }
-    else
-    {
-        const uint32_t work = xcd_contiguous(blockIdx.x, nblocks);
-        group = work % GROUPS;
-        tx = (work / GROUPS) % tiles_x;
-        ty = (work / GROUPS) / tiles_x;
-    }
-    const int i0 = int(group) * CPW;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int qy0 = int(ty) * FRL_ROWS - a.radius_y; // extended image row of the tile's first row
-    const int qx0 = int(tx) * 256 - a.radius_x;      // … and column
-    const uint32_t lds_base = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((__attribute__((address_space(3))) void *)lds)));
-    const focus_const_int_ptr shifts = (focus_const_int_ptr)(uintptr_t)w.shifts;
-    const uint32_t row_b = uint32_t(w.Wp) * 4u;
-    // this wave's pieces of a patch: piece p = 64·j + lane (16 bytes) is row p / 68, bytes 16·(p % 68) … of the row; j = wave, wave + 4, …
-    uint32_t rel[5];
-#pragma unroll
-    for(int jj = 0; jj < 5; jj++)
-    {
-        const uint32_t pp = uint32_t(64 * (wave + 4 * jj) + lane);
-        rel[jj] = (pp / 68u) * row_b + (pp % 68u) * 16u;
-    }
-    RangeAcc4 acc[2][CPW];
-#pragma unroll
-    for(int r = 0; r < 2; r++)
-#pragma unroll
-        for(int c = 0; c < CPW; c++)
-            acc[r][c].init();
-    const int n_ids = a.n_focus_ids;
-    for(int k = 0; k < n_ids; k += 2)
-    {
-        int sx[2][CPW], sy[2][CPW], ox[2], oy[2];
-#pragma unroll
-        for(int v = 0; v < 2; v++)
-        {
-            const int kv = min(k + v, n_ids - 1); // an odd tail reduces the last view twice: no minimum or maximum changes
-#pragma unroll
-            for(int c = 0; c < CPW; c++)
-            {
-                sx[v][c] = shifts[4 * ((i0 + c) * FOCUS_MAX_IDS + kv)];
-                sy[v][c] = shifts[4 * ((i0 + c) * FOCUS_MAX_IDS + kv) + 1];
-            }
-            ox[v] = min(min(sx[v][0], sx[v][1]), min(sx[v][2], sx[v][3]));
-            oy[v] = min(min(sy[v][0], sy[v][1]), min(sy[v][2], sy[v][3]));
-        }
-        __builtin_amdgcn_s_barrier(); // everybody is done reading the previous step's patches
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for(int v = 0; v < 2; v++)
-        {
-            const int kv = min(k + v, n_ids - 1);
-            // (wave-uniform by construction; readfirstlane makes it a fact for the register allocator — an "s" asm operand cannot take the vector
-            // registers the compiler keeps the pointer in when its uniformity analysis gives up)
-            const uint64_t bv = reinterpret_cast<uint64_t>(reinterpret_cast<const uint8_t *>(w.pad) +
-                                                           (((size_t)kv * w.Hp + (size_t)(qy0 + oy[v] + w.Py)) * w.Wp + (size_t)(qx0 + ox[v] + w.Px)) * 4);
-            const uint8_t *base = reinterpret_cast<const uint8_t *>(uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(bv))))) |
-                                                                    (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(bv >> 32))))) << 32));
-#pragma unroll
-            for(int jj = 0; jj < 5; jj++)
-            {
-                const int j = wave + 4 * jj;
-                if(j < PIECES) // wave-uniform
-                    dma16_s(base, rel[jj], lds_base + uint32_t(v) * FRL_PATCH_B + uint32_t(j) * 1024u);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces have landed
-        __builtin_amdgcn_s_barrier();                     // … and everybody else's
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for(int r = 0; r < 2; r++)
-#pragma unroll
-            for(int c = 0; c < CPW; c++)
-            {
-                const uint32_t *pa = lds + ((2 * wave + r) + (sy[0][c] - oy[0])) * FRL_PATCH_W + (sx[0][c] - ox[0]) + lane;
-                const uint32_t *pb = lds + FRL_PATCH_B / 4 + ((2 * wave + r) + (sy[1][c] - oy[1])) * FRL_PATCH_W + (sx[1][c] - ox[1]) + lane;
-                const u32x4 va = {pa[0], pa[64], pa[128], pa[192]}, vb = {pb[0], pb[64], pb[128], pb[192]};
-                acc[r][c].add2(va, vb);
-            }
-    }
-    // E: a lane holds the pixels lane + 64t; the four u16 of a (row, candidate) pair go through this wave's corner of the patch buffer so that
-    // every lane stores the eight bytes of pixels 4·lane … 4·lane + 3, like focus_range
-    __builtin_amdgcn_s_barrier(); // the patches are dead
-    asm volatile("" ::: "memory");
-    uint16_t *stage = reinterpret_cast<uint16_t *>(lds) + wave * (2 * CPW * 256);
-#pragma unroll
-    for(int r = 0; r < 2; r++)
-#pragma unroll
-        for(int c = 0; c < CPW; c++)
-        {
-            const u32x2 e = acc[r][c].encode();
-            uint16_t *row = stage + (r * CPW + c) * 256;
-            row[lane] = static_cast<uint16_t>(e.x);
-            row[64 + lane] = static_cast<uint16_t>(e.x >> 16);
-            row[128 + lane] = static_cast<uint16_t>(e.y);
-            row[192 + lane] = static_cast<uint16_t>(e.y >> 16);
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the u16 stores above and the 8-byte reads below alias through different types
-#pragma unroll
-    for(int r = 0; r < 2; r++)
-    {
-        const int ey = int(ty) * FRL_ROWS + 2 * wave + r;
-        if(ey < w.He_p) // wave-uniform: the last tile of an image whose extended height is not a multiple of 8
-        {
-#pragma unroll
-            for(int c = 0; c < CPW; c++)
-            {
-                const u32x2 out = *reinterpret_cast<const u32x2 *>(stage + (r * CPW + c) * 256 + 4 * lane);
-                uint16_t *dst = w.E + ((size_t)(i0 + c) * w.He_p + ey) * w.We_p + tx * 256 + 4 * lane;
-                *reinterpret_cast<u32x2 *>(dst) = out;
-            }
-        }
     }
 }
 

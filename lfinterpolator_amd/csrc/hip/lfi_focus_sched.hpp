@@ -46,24 +46,7 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     w.Py = Sy + ry;
     w.Wp = (w.Px + std::max(W + Sx + rx, w.We_p - rx + Sx) + 3) / 4 * 4;
     w.Hp = w.Py + std::max(H + Sy + ry, w.He_p - ry + Sy);
-    // + 16 rows and 64 bytes of slack behind the last plane: focus_range_lds always fetches a whole 16 × 272-pixel patch
-    const size_t pad_bytes = sizeof(uint32_t) * ((size_t)ctx->n_focus_ids * w.Hp + lfi::FRL_PATCH_ROWS) * w.Wp + 64;
-    // Can the range pass stage its samples through LDS (focus_range_lds)?  Within every group of four consecutive candidates a view's integer
-    // shifts — floor(f_i · offset), the device's own arithmetic (focus_plan_shifts) — must span at most 16 pixels and 8 rows.
-    bool range_lds = ctx->focus_variant == 0;
-    for(size_t k = 0; k < ctx->h_focus_offsets.size() && range_lds; k++)
-        for(int i0 = 0; i0 < lfi::FOCUS_STEPS && range_lds; i0 += 4)
-        {
-            int lo[2] = {INT32_MAX, INT32_MAX}, hi[2] = {INT32_MIN, INT32_MIN};
-            for(int i = i0; i < i0 + 4; i++)
-            {
-                const float f = std::fmaf(step, static_cast<float>(i), ctx->focus);
-                const int sx = static_cast<int>(std::floor(static_cast<double>(f) * static_cast<double>(ctx->h_focus_offsets[k].x)));
-                const int sy = static_cast<int>(std::floor(static_cast<double>(f) * static_cast<double>(ctx->h_focus_offsets[k].y)));
-                lo[0] = std::min(lo[0], sx), hi[0] = std::max(hi[0], sx), lo[1] = std::min(lo[1], sy), hi[1] = std::max(hi[1], sy);
-            }
-            range_lds = hi[0] - lo[0] <= lfi::FRL_MAX_DX && hi[1] - lo[1] <= lfi::FRL_MAX_DY;
-        }
+    const size_t pad_bytes = sizeof(uint32_t) * (size_t)ctx->n_focus_ids * w.Hp * w.Wp;
     if(pad_bytes > ((size_t)16 << 30))
         return LFI_OK;
     size_t at = 0;
@@ -156,15 +139,6 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     }
     LFI_HIP(ctx, hipEventRecord(ctx->ev_pad, st));
     const uint32_t tiles_x = uint32_t(w.We_p / 256), tiles_y = uint32_t(w.He_p / 4);
-    if(range_lds)
-    {
-        constexpr int GROUPS = lfi::FOCUS_STEPS / 4;
-        const uint32_t tiles_y8 = (uint32_t(w.He_p) + lfi::FRL_ROWS - 1) / lfi::FRL_ROWS;
-        const int striped = tiles_x >= 8;
-        const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(tiles_x, tiles_y8, GROUPS) : tiles_x * tiles_y8 * GROUPS;
-        hipLaunchKernelGGL(lfi::focus_range_lds, dim3(nblocks), dim3(256), 0, st, a, w, nblocks, striped);
-    }
-    else
     {
         constexpr int CPW = 4, GROUPS = lfi::FOCUS_STEPS / CPW;
         const int striped = tiles_x >= 8;
