@@ -37,10 +37,25 @@
 namespace lfi {
 
 constexpr int SX_QCAP = 128; // queued (pixel, view, channel) sums per wave and tile: two per lane
-// measurement builds only (hipcc -DLFI_SX_ABL=1, tools/stdx_ablate.sh): no chain arithmetic (the C units still fetch); the output is wrong
-// by construction.  (Rounds of ablations without the C units or the band test: profiles/r03_stdx_ablation_*.txt, an earlier form of the kernel.)
+// measurement builds only (hipcc -DLFI_SX_ABL=n, tools/stdx_ablate.sh): 1 no chain arithmetic (the C units still fetch), 2 no byte
+// patches, 3 no second fetch of the last chunk, 4 no band test (nothing queued), 5 no RGBA stores, 6 every tile's RGBA stores into the first
+// tile's bytes (stores that stay in the L2); the output is wrong by construction.  (Rounds of ablations without the C units or the band test: profiles/r03_stdx_ablation_*.txt, an earlier form of the kernel.)
 #ifndef LFI_SX_ABL
 #define LFI_SX_ABL 0
+#endif
+#ifndef LFI_SX_PHASE
+#define LFI_SX_PHASE 0
+#endif
+#ifndef LFI_SX_NT
+#define LFI_SX_NT 1 // 0: ordinary stores instead of nontemporal ones (measurement)
+#endif
+// measurement builds (-DLFI_SX_TRACE=1, tools/stdx_trace.sh): per workgroup and unit slot, the clocks wave 0 spent in the wait + barrier and in
+// the unit's work, summed over the tiles (lfi_debug_sx_trace reads them back)
+#ifndef LFI_SX_TRACE
+#define LFI_SX_TRACE 0
+#endif
+#if LFI_SX_TRACE
+__device__ unsigned long long lfi_sx_trace_buf[1024 * 32];
 #endif
 
 // The ring buffer of unit `sl` (0 … 2·NCH − 2: M(NCH−1) … M(1), MC(0), C(1) … C(NCH−1)) of a workgroup's j-th tile.  Fetches run two units
@@ -99,11 +114,24 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
     for(int s = 0; s < 2 * NCH; s++)
         asm volatile("" : "+v"(wreg[s]));
 
+#if LFI_SX_TRACE
+    __shared__ unsigned long long tr[32];
+    if(threadIdx.x < 32)
+        tr[threadIdx.x] = 0ull;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     const int G = gridDim.x;
     const int t0 = int(xcd_contiguous(blockIdx.x, gridDim.x));
     if(t0 >= n_tiles)
         return;
     __syncthreads(); // the offset table is complete
+#if LFI_SX_PHASE
+    // measurement builds: the second workgroup of every CU (dispatch order: XCD = id % 8, CU = (id / 8) % 32) starts late, so that the
+    // two workgroups of a CU are not in the same unit of their tiles (≥ 16: every other workgroup of an XCD instead)
+    if((blockIdx.x >> 3) & (LFI_SX_PHASE >= 16 ? 1 : 32))
+        for(int i = 0; i < (LFI_SX_PHASE & 15); i++)
+            __builtin_amdgcn_s_sleep(127);
+#endif
 
     // ---- LDS-DMA of one unit: blend_p3's pieces (wave w moves octets w and w + 4 of every channel) ----------------------------------
     struct Pieces
@@ -209,7 +237,8 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
 
     // ---- the chain over one chunk for this lane's queued sums, from buffer `buf` (images ascending: src/kernels.cu:328-338) ----------
     // A queued sum = (pixel of the tile, view of the wave, channel) packed as px | v16 << 7 | ch << 11, and its running value s15 =
-    // 2^15 · (the reference's running sum): a power-of-two scaling commutes with every rounding.
+    // 2^-9 · (the reference's running sum; weights ×2^15, bytes ×2^-24): a power-of-two scaling commutes with every rounding (no partial
+    // sum leaves the normal range: the smallest non-zero product is 2^-48).
     // weights: the wave's A fragments, fetched across lanes (view v16's images 32ks + 8kq + j sit in lane v16 + 16kq, dword j/2).
     // All LDS traffic of a k-step — 32 pixel bytes, 16 weight pairs — is issued BEFORE its first fma (staging registers + a scheduling
     // barrier): written as read → convert → fma per image the compiler emitted exactly that, one LDS latency per image (0.6 ms of
@@ -248,14 +277,18 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
             {
                 const uint32_t pair = w2[kk >> 1];
                 const float w = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(kk & 1 ? pair >> 16 : pair)));
-                s = __builtin_fmaf(static_cast<float>(pbyte[kk]), w, s); // addWeighted, src/kernels.cu:292-299
+                // the byte AS an fp16 subnormal (= byte·2^-24, what the MFMA's B operand holds too): v_fma_mix_f32 widens both halves
+                // itself, no v_cvt_f32_ubyte
+                const float pf = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(pbyte[kk])));
+                s = __builtin_fmaf(pf, w, s); // addWeighted, src/kernels.cu:292-299
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         s15 = s;
     };
     // (unsigned char)__float2int_rn(sum) (uch4, src/kernels.cu:301-310): + 2^23 rounds to nearest-even and leaves the integer in the low bits
-    auto byte_of = [](const float s15) { return __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; };
+    auto byte_of15 = [](const float s15) { return __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; }; // the spill path's scale
+    auto byte_of = [](const float s9) { return __builtin_bit_cast(uint32_t, s9 * 0x1p9f + 8388608.0f) & 0xffu; };
 
     // ---- the unit sequence of this workgroup: tiles t0, t0 + G, … (T of them), 2·NCH − 1 units each ------------------------------------
     // (The C units of a tile interleaved with the next tile's M units, so that no fetch is issued with two short units of lead, measured
@@ -265,7 +298,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
     auto slot_chunk = [](const int sl) { return sl < NCH ? NCH - 1 - sl : sl - NCH + 1; };
     // C(1) and C(2) read the buffers M(1) and M(2) left: nothing was fetched into them in between (sx_buffer: only C(3)'s chunk was
     // overwritten, by MC(0)'s)
-    auto slot_fetches = [](const int sl) { return sl < NCH || sl > NCH + 1; };
+    auto slot_fetches = [](const int sl) { return sl < NCH || (sl > NCH + 1 && LFI_SX_ABL != 3); };
     int ij = 0, isl = 0; // issue cursor: the next unit to fetch; past the end when ij ≥ T
     auto advance_issue = [&] {
         do
@@ -307,6 +340,9 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
         constexpr int cc = sl < NCH ? NCH - 1 - sl : sl - NCH + 1;
         constexpr bool is_last_c = sl == NU - 1;
         const int buf = sx_buffer<NCH>(cj, sl);
+#if LFI_SX_TRACE
+        const unsigned long long tA = __builtin_amdgcn_s_memtime();
+#endif
         const int allowed = st2 + (have1 ? nd1 : 0) + st1;
         switch(min(allowed, 63) >> 2)
         {
@@ -329,6 +365,9 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
         }
         __builtin_amdgcn_s_barrier(); // everybody's pieces of this unit have landed; everybody is done with the previous unit's buffer
         asm volatile("" ::: "memory");
+#if LFI_SX_TRACE
+        const unsigned long long tB = __builtin_amdgcn_s_memtime();
+#endif
         const bool have2 = have1 && ij < T;
         int nd2 = 0;
         if(have2)
@@ -358,7 +397,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
 #pragma unroll
                 for(int b = 0; b < 8; b++)
                     px_ok |= (x0 + 8 * n + b < W) ? 7u << (3 * b) : 0u;
-                uint8_t *ubase = a.views + (((size_t)vw0 * a.out_rows + ty) * W + x0) * 4;
+                uint8_t *ubase = a.views + (((size_t)vw0 * a.out_rows + (LFI_SX_ABL == 6 ? 0 : ty)) * W + (LFI_SX_ABL == 6 ? 0 : x0)) * 4;
                 const size_t vstride = (size_t)a.out_rows * W * 4; // bytes between consecutive views
                 const bool full_x = x0 + 8 * n + 8 <= W;
 #pragma unroll
@@ -379,7 +418,8 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                             const float dist = v - (t - 16384.0f);
                             const float pow2 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v + bmax_acc) & 0x7f800000u);
                             const float inside = __builtin_fmaf(-chain_acc, pow2, base_acc);
-                            mask[i] |= __builtin_fabsf(dist) > inside ? 1u << (3 * b + ch) : 0u;
+                            if constexpr(LFI_SX_ABL != 4)
+                                mask[i] |= __builtin_fabsf(dist) > inside ? 1u << (3 * b + ch) : 0u;
                             bits[ch] = __builtin_bit_cast(uint32_t, t);
                         }
                         const uint32_t rg = __builtin_amdgcn_perm(bits[1], bits[0], 0x0c0c0400u); // [R, G, 0, 0]
@@ -390,10 +430,10 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                     uint32_t *out = reinterpret_cast<uint32_t *>(ubase + (size_t)(4 * kg + i) * vstride) + 8 * n;
                     if(full_x)
                     {
-                        if(view_ok)
+                        if(view_ok && LFI_SX_ABL != 5)
                         {
                             const u32x4 lo4 = {rgba[0], rgba[1], rgba[2], rgba[3]}, hi4 = {rgba[4], rgba[5], rgba[6], rgba[7]};
-                            if constexpr(NT_STORE)
+                            if constexpr(NT_STORE && LFI_SX_NT)
                             {
                                 __builtin_nontemporal_store(lo4, reinterpret_cast<u32x4_a4 *>(out));
                                 __builtin_nontemporal_store(hi4, reinterpret_cast<u32x4_a4 *>(out + 4));
@@ -457,7 +497,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                                 const float w = static_cast<float>(__builtin_bit_cast(_Float16, wrow[g]));
                                 s = __builtin_fmaf(static_cast<float>(p), w, s);
                             }
-                            (ubase + (size_t)(4 * kg + i_sel) * vstride)[(8 * n + int(b)) * 4 + int(ch)] = static_cast<uint8_t>(byte_of(s));
+                            (ubase + (size_t)(4 * kg + i_sel) * vstride)[(8 * n + int(b)) * 4 + int(ch)] = static_cast<uint8_t>(byte_of15(s));
                         }
                     }
                     count += __builtin_popcountll(m);
@@ -475,7 +515,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                 if(queued > 64)
                     chain(std::integral_constant<int, cc>{}, buf, kc, entry1, s1);
             }
-            if constexpr(is_last_c)
+            if constexpr(is_last_c && LFI_SX_ABL != 2)
             {
                 // the chain's bytes over the rounded ones (not counted in st1: an undercount is safe)
                 uint8_t *ubase = a.views + (((size_t)vw0 * a.out_rows + ty) * W + x0) * 4;
@@ -486,6 +526,23 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                     (ubase + (size_t)((entry1 >> 7) & 15u) * vstride)[(entry1 & 127u) * 4u + (entry1 >> 11)] = static_cast<uint8_t>(byte_of(s1));
             }
         }
+#if LFI_SX_TRACE
+        {
+            const unsigned long long tC = __builtin_amdgcn_s_memtime();
+            if(threadIdx.x == 0)
+            {
+                tr[2 * sl] += tB - tA;
+                tr[2 * sl + 1] += tC - tB;
+                if constexpr(is_mc)
+                {
+                    tr[15] += (unsigned long long)queued;
+                    tr[16] += queued > 64;
+                    tr[17] += queued == 0;
+                    tr[18] += queued >= SX_QCAP;
+                }
+            }
+        }
+#endif
         if(!have1)
             return false;
         have1 = have2;
@@ -501,6 +558,13 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
         });
         cj++;
     }
+#if LFI_SX_TRACE
+    if(threadIdx.x == 0)
+        tr[14] = __builtin_amdgcn_s_memtime() - t_begin;
+    __syncthreads();
+    if(threadIdx.x < 32 && blockIdx.x < 1024)
+        lfi_sx_trace_buf[blockIdx.x * 32 + threadIdx.x] = tr[threadIdx.x];
+#endif
 }
 
 } // namespace lfi

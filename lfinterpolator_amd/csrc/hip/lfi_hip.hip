@@ -1463,5 +1463,12 @@ int lfi_debug_mfma_f16_chain(lfi_ctx *ctx, int shape, int k, const uint16_t *a_3
     return LFI_OK;
 }
 
+#if LFI_SX_TRACE
+// measurement builds only (blend_stdx.hpp): the per-workgroup unit clocks of the last blend_stdx launch; not part of include/lfi.h
+int lfi_debug_sx_trace(unsigned long long *out, int n_words)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(lfi::lfi_sx_trace_buf), sizeof(unsigned long long) * std::min(n_words, 1024 * 32)) == hipSuccess ? 0 : 1;
+}
+#endif
 } // extern "C"
 

@@ -3,8 +3,8 @@
 : ${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_ab gpurun_out
-for n in 1; do
+for n in ${SX_ABL:-1 2 3 4 5}; do
   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -DLFI_SX_ABL=$n -shared -o gpurun_ab/liblfi_sx$n.so lfinterpolator_amd/csrc/hip/lfi_hip.hip -ldl 2> gpurun_out/stdx_build_$n.log || exit 1
 done
 { echo "== as built"; python3 tools/std15_time.py 2>&1 | grep stdx
-  for n in 1; do echo "== LFI_SX_ABL=$n"; LFI_AB_LIB=gpurun_ab/liblfi_sx$n.so python3 tools/std15_time.py 2>&1 | grep stdx; done; } | tee gpurun_out/stdx_ablate.txt
+  for n in ${SX_ABL:-1 2 3 4 5}; do echo "== LFI_SX_ABL=$n"; LFI_AB_LIB=gpurun_ab/liblfi_sx$n.so python3 tools/std15_time.py 2>&1 | grep stdx; done; } | tee gpurun_out/stdx_ablate.txt
