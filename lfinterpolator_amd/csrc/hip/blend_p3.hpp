@@ -54,6 +54,16 @@ __host__ __device__ constexpr int p3_octet_off(int o)
 
 #define LFI_P3_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+// measurement builds (-DLFI_P3_TRACE=1, tools/p3_trace.sh): per workgroup, the clocks wave 0 spends in the parts of a unit, summed over its
+// units (lfi_debug_p3_trace reads them back).  A stamp drains the wave's LDS operations first: it perturbs what it measures a little.
+#ifndef LFI_P3_TRACE
+#define LFI_P3_TRACE 0
+#endif
+#if LFI_P3_TRACE
+__device__ unsigned long long lfi_p3_trace_buf[1024 * 8];
+#define LFI_P3_STAMP(var) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#endif
+
 template <int N, int I = 0, typename F>
 __device__ __forceinline__ void p3_for_each_chunk(F &&f)
 {
@@ -153,7 +163,7 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
     {
         int ox[OPW], oy[OPW];
         uint32_t img_off[OPW]; // (this lane's image − the octet's first image) · 3 planes, in bytes (< 2^32: checked on the host)
-        int g_base[OPW];       // the octet's first image (wave-uniform), clamped to the last image
+        const uint8_t *sbase[OPW]; // the R plane of the octet's first image (wave-uniform; that image clamped to the last one)
     };
     auto lookup = [&](const int chunk) {
         Pieces pc;
@@ -167,16 +177,50 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
             pc.ox[o2] = o.x;
             pc.oy[o2] = o.y;
             pc.img_off[o2] = uint32_t(dg) * 3u * uint32_t(shift_stride);
-            pc.g_base[o2] = g_base;
+            pc.sbase[o2] = a.planar + (size_t)__builtin_amdgcn_readfirstlane(g_base) * 3 * shift_stride;
         }
         return pc;
     };
+    // A cursor over this workgroup's tiles t0, t0 + G, …: the tile's row and column are stepped, not divided out per unit (odd launches walk
+    // the image backwards: see launch_p3).  One integer division per cursor and kernel instead of one per unit and use.
+    struct TileCursor
+    {
+        int ty, tx;
+    };
+    const int step_y = G / tiles_x, step_x = G - step_y * tiles_x;
+    auto cursor_at = [&](const int t_seq) {
+        const int t = reverse ? n_tiles - 1 - t_seq : t_seq;
+        TileCursor c;
+        c.ty = t / tiles_x;
+        c.tx = t - c.ty * tiles_x;
+        return c;
+    };
+    auto cursor_step = [&](TileCursor &c) { // t_seq += G
+        if(reverse)
+        {
+            c.tx -= step_x;
+            c.ty -= step_y;
+            if(c.tx < 0)
+            {
+                c.tx += tiles_x;
+                c.ty--;
+            }
+        }
+        else
+        {
+            c.tx += step_x;
+            c.ty += step_y;
+            if(c.tx >= tiles_x)
+            {
+                c.tx -= tiles_x;
+                c.ty++;
+            }
+        }
+    };
     // returns the number of DMA instructions issued by this wave (wave-uniform)
-    auto issue = [&](const int t_seq, const int chunk, const int buf, const Pieces &pc) {
-        const int t = reverse ? n_tiles - 1 - t_seq : t_seq; // odd launches walk the image backwards: see launch_p3
-        const int ty = t / tiles_x;
-        const int y = a.out_y0 + ty;
-        const int x0 = (t - ty * tiles_x) * P3_TPX;
+    auto issue = [&](const TileCursor &tc, const int chunk, const int buf, const Pieces &pc) {
+        const int y = a.out_y0 + tc.ty;
+        const int x0 = tc.tx * P3_TPX;
         const int kc = min(P3_KC, a.k_pad - P3_KC * chunk);
         const uint32_t dst = lds_base + uint32_t(buf) * P3_BUF_B;
         int count = 0;
@@ -191,7 +235,7 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
             const int start = x0 + pc.ox[o2] + a.planar_padx; // any byte of the plane row (byte-aligned LDS-DMA: blend_planar.hpp)
             // sy·pitch with a full-rate 24-bit multiply (rows, pitch < 2^24; an octet's 24 planes < 2^32 bytes: checked on the host)
             const uint32_t voff = pc.img_off[o2] + __umul24(uint32_t(sy), uint32_t(a.planar_pitch)) + uint32_t(start) + 16u * uint32_t(lane & 7);
-            const uint8_t *sbase = a.planar + (size_t)__builtin_amdgcn_readfirstlane(pc.g_base[o2]) * 3 * shift_stride;
+            const uint8_t *sbase = pc.sbase[o2];
             if constexpr(ABL != 2)
             {
 #pragma unroll
@@ -271,10 +315,9 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
     // epilogue of tile t: quantise (acc = S·2^-9), pack eight pixels per (view, channel), store; returns the number of store
     // instructions issued (wave-uniform)
     const uint32_t plane_b = uint32_t(a.out_rows) * uint32_t(a.views_pitch); // bytes of one byte plane (< 2^26·… checked on the host)
-    auto epilogue = [&](const f32x4 (&acc)[8][3], const int t_seq, const int vw, const int nvalid) {
-        const int t = reverse ? n_tiles - 1 - t_seq : t_seq;
-        const int ty = t / tiles_x; // row inside the output window
-        const int x0 = (t - ty * tiles_x) * P3_TPX;
+    auto epilogue = [&](const f32x4 (&acc)[8][3], const TileCursor &tc, const int vw, const int nvalid) {
+        const int ty = tc.ty; // row inside the output window
+        const int x0 = tc.tx * P3_TPX;
         uint32_t hq[48]; // [(i·3 + channel)·4 + block pair]: two halves, 0x4000 | byte after the rounding-mode window
 #pragma unroll
         for(int i = 0; i < 4; i++)
@@ -352,15 +395,17 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
 
     // ---- the unit sequence of this workgroup: tiles t0, t0 + G, …; chunks 0 … NCH−1 of each -------------------------------------
     int it = t0, ic = 0; // issue cursor: the next unit to fetch
+    TileCursor itc = cursor_at(t0);
     auto advance_issue = [&] {
         if(++ic == NCH)
         {
             ic = 0;
             it += G;
+            cursor_step(itc);
         }
     };
     Pieces pc = lookup(0);
-    issue(it, ic, 0, pc);
+    issue(itc, ic, 0, pc);
     advance_issue();
     if constexpr(NCH > 1)
         pc = lookup(ic);
@@ -368,12 +413,17 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
     int nd1 = 0;               // its DMA instructions
     if(have1)
     {
-        nd1 = issue(it, ic, 1, pc);
+        nd1 = issue(itc, ic, 1, pc);
         advance_issue();
         if constexpr(NCH > 1)
             pc = lookup(ic);
     }
-    int ct = t0, buf = 0; // compute cursor (the chunk is the compile-time argument of `unit`)
+    int buf = 0;
+    TileCursor ctc = cursor_at(t0); // compute cursor (the chunk is the compile-time argument of `unit`)
+#if LFI_P3_TRACE
+    unsigned long long tr_wait = 0ull, tr_issue = 0ull, tr_kloop = 0ull, tr_drain = 0ull, tr_epi = 0ull, tr_units = 0ull, tr_begin;
+    LFI_P3_STAMP(tr_begin);
+#endif
     int st1 = 0, st2 = 0; // store instructions of the previous unit's epilogue and of the one before
     // One unit; the chunk index is a compile-time constant (the loop below is unrolled over the chunks of a tile), so the chunk's
     // weight fragments are registers named at compile time — a runtime index would put them into scratch, and wave-uniform selects
@@ -382,6 +432,10 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
         constexpr int cc = decltype(cc_tag)::value;
         // VMEM operations of this wave younger than the current unit's DMA: stores(u−2), DMA(u+1), stores(u−1) — they may stay in
         // flight; vmcnt retires in order, so "at most that many outstanding" means the current unit's pieces have landed
+#if LFI_P3_TRACE
+        unsigned long long tA, tB, tC, tD;
+        LFI_P3_STAMP(tA);
+#endif
         const int allowed = st2 + (have1 ? nd1 : 0) + st1;
         switch(min(allowed, 63) >> 2) // (VG 2: up to 24 + 12 + 24)
         {
@@ -404,16 +458,25 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
         }
         __builtin_amdgcn_s_barrier(); // everybody's pieces of this unit have landed; everybody is done with the previous unit's buffer
         asm volatile("" ::: "memory");
+#if LFI_P3_TRACE
+        LFI_P3_STAMP(tB);
+#endif
         const bool have2 = have1 && it < n_tiles;
         int nd2 = 0;
         if(have2)
         {
-            nd2 = issue(it, ic, buf == 0 ? 2 : buf - 1, pc); // (buf + 2) % 3: the buffer the previous unit used
+            nd2 = issue(itc, ic, buf == 0 ? 2 : buf - 1, pc); // (buf + 2) % 3: the buffer the previous unit used
             advance_issue();
             if constexpr(NCH > 1)
                 pc = lookup(ic); // for the unit after that: off the critical path of the next barrier
         }
         const int kc = min(P3_KC, a.k_pad - P3_KC * cc);
+#if LFI_P3_TRACE
+        LFI_P3_STAMP(tC);
+        tr_wait += tB - tA;
+        tr_issue += tC - tB;
+        tr_units++;
+#endif
         st2 = st1;
         st1 = 0;
         if constexpr(NCH == 1)
@@ -436,6 +499,10 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
                         wk[vg][1] = pass == 0 ? wreg[vg][1] : wmore[pass > 0 ? pass - 1 : 0][vg][1];
                     }
                     compute(wk, buf, kc, std::true_type{});
+#if LFI_P3_TRACE
+                    LFI_P3_STAMP(tD);
+                    tr_kloop += tD - tC;
+#endif
                     // Single-pass launches: all of this wave's fetches (the two units in flight) land before its stores go out.
                     // Measured, not designed — round 2's kernel held such a wait by accident (the compiler's, for pass-weight loads
                     // that a one-pass launch never issues); without it config 2 runs 2–3 % and one rank of config 4 15 % slower, placed
@@ -444,10 +511,22 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
                     // chunks are slower with it.
                     if constexpr(MP == 1)
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if LFI_P3_TRACE
+                    {
+                        unsigned long long tE;
+                        LFI_P3_STAMP(tE);
+                        tr_drain += tE - tD;
+                        tD = tE;
+                    }
+#endif
 #pragma unroll
                     for(int vg = 0; vg < VG; vg++)
                         if(nvalid > 16 * vg) // wave-uniform
-                            st1 += epilogue(acc[vg], ct, vw + 16 * vg, min(nvalid - 16 * vg, 16));
+                            st1 += epilogue(acc[vg], ctc, vw + 16 * vg, min(nvalid - 16 * vg, 16));
+#if LFI_P3_TRACE
+                    LFI_P3_STAMP(tC);
+                    tr_epi += tC - tD;
+#endif
                 }
             });
         }
@@ -464,19 +543,27 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
                     wk[vg][1] = wreg[vg][2 * cc + 1];
                 }
                 compute(wk, buf, kc, std::integral_constant<bool, cc == 0>{}); // chunk 0 starts from a zero C operand: no clears
+#if LFI_P3_TRACE
+                LFI_P3_STAMP(tD);
+                tr_kloop += tD - tC;
+#endif
                 if constexpr(cc == NCH - 1)
                 {
 #pragma unroll
                     for(int vg = 0; vg < VG; vg++)
                         if(nvalid > 16 * vg) // wave-uniform
-                            st1 += epilogue(acc[vg], ct, vw0 + 16 * vg, min(nvalid - 16 * vg, 16));
+                            st1 += epilogue(acc[vg], ctc, vw0 + 16 * vg, min(nvalid - 16 * vg, 16));
+#if LFI_P3_TRACE
+                    LFI_P3_STAMP(tC);
+                    tr_epi += tC - tD;
+#endif
                 }
             }
         }
         if(!have1)
             return false;
         if constexpr(cc == NCH - 1)
-            ct += G;
+            cursor_step(ctc);
         buf = buf == 2 ? 0 : buf + 1;
         have1 = have2;
         nd1 = nd2;
@@ -488,6 +575,15 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
             if(more)
                 more = unit(cc_tag);
         });
+#if LFI_P3_TRACE
+    if(threadIdx.x == 0 && blockIdx.x < 1024)
+    {
+        unsigned long long t_end;
+        LFI_P3_STAMP(t_end);
+        unsigned long long *o = lfi_p3_trace_buf + blockIdx.x * 8;
+        o[0] = tr_wait, o[1] = tr_issue, o[2] = tr_kloop, o[3] = tr_drain, o[4] = tr_epi, o[5] = tr_units, o[6] = t_end - tr_begin, o[7] = gridDim.x;
+    }
+#endif
 }
 
 // ---- layout conversions for the planar view layout ------------------------------------------------------------------------------
