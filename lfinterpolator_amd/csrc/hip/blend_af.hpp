@@ -245,7 +245,8 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
     const float bmax_acc = (c0 + nf * 0x1p-16f) * 0x1p-9f;
     const float base_acc = (0.5f - c0) * 0x1p-9f;
     const float chain_acc = nf * 0x1p-24f;
-    auto byte_of = [](const float s15) { return __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; };
+    auto byte_of15 = [](const float s15) { return __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; }; // the overflow path's scale (bytes as integers)
+    auto byte_of = [](const float s9) { return __builtin_bit_cast(uint32_t, s9 * 0x1p9f + 8388608.0f) & 0xffu; };     // the chain's: 2^-9 · sum
 
     // ---- the chain over chunk CC for a queued sum = pixel of the wave (5 bits) | view of the wave << 5 (5 bits) | channel << 11 ------------
     // pixel bytes from the chunk's slot; weights from the wave's A fragments across lanes (view v's images 16ks + 8hh + j: lane v + 32hh,
@@ -283,7 +284,8 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
             {
                 const uint32_t pair = w2[ks & 1][j >> 1];
                 const float w = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(j & 1 ? pair >> 16 : pair)));
-                s = __builtin_fmaf(static_cast<float>(pbyte[ks & 1][j]), w, s); // addWeighted, src/kernels.cu:292-299
+                // the byte AS an fp16 subnormal (byte·2^-24): v_fma_mix_f32 widens both halves itself, no v_cvt_f32_ubyte per image (blend_stdx.hpp)
+                s = __builtin_fmaf(static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(pbyte[ks & 1][j]))), w, s); // addWeighted, src/kernels.cu:292-299
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -480,7 +482,7 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
                             const float w = static_cast<float>(__builtin_bit_cast(_Float16, wrow[g]));
                             s = __builtin_fmaf(static_cast<float>(p), w, s);
                         }
-                        (plane0 + ((size_t)view * oplane_px + r) * 4)[c] = static_cast<uint8_t>(byte_of(s));
+                        (plane0 + ((size_t)view * oplane_px + r) * 4)[c] = static_cast<uint8_t>(byte_of15(s));
                     }
                 }
                 count += n;

@@ -84,8 +84,9 @@ __device__ __forceinline__ int store_tile_filtered(const KernelArgs &a, f32x16 (
         const int vrel = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * (src >> 5), pxl = src & 31;
         const uint8_t *pb = px + (size_t)(c * KC) * TPX + pxl;
         const u32x4 *wb = reinterpret_cast<const u32x4 *>(wh) + vrel; // this view's eight ×2^15 halves of a k-octet
-        // the chain on the ×2^15 weights: a power-of-two scaling commutes with every rounding (no overflow: sums < 2^24), so
-        // s15 = 2^15 · (the reference's running sum) exactly
+        // the chain on the ×2^15 weights and the bytes AS fp16 subnormals (byte·2^-24: v_fma_mix_f32 widens both halves itself, no
+        // v_cvt_f32_ubyte per image): a power-of-two scaling commutes with every rounding (nothing leaves the normal range: the
+        // smallest non-zero product is 2^-48, sums stay below 2^0), so s15 = 2^-9 · (the reference's running sum) exactly
         float s15 = 0.0f;
         for(int o = 0; 8 * o < kc; o++)
         {
@@ -95,10 +96,11 @@ __device__ __forceinline__ int store_tile_filtered(const KernelArgs &a, f32x16 (
             {
                 const uint32_t pair = w8[j >> 1];
                 const float w = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(j & 1 ? pair >> 16 : pair)));
-                s15 = __builtin_fmaf(static_cast<float>(pb[(8 * o + j) * TPX]), w, s15); // addWeighted, src/kernels.cu:292-299
+                const float pf = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(pb[(8 * o + j) * TPX])));
+                s15 = __builtin_fmaf(pf, w, s15); // addWeighted, src/kernels.cu:292-299
             }
         }
-        const uint32_t byte = __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; // (unsigned char)__float2int_rn(sum)
+        const uint32_t byte = __builtin_bit_cast(uint32_t, s15 * 0x1p9f + 8388608.0f) & 0xffu; // (unsigned char)__float2int_rn(sum)
         if(lane < n)
             plane0[((size_t)vrel * oplane_px + pxl) * 4 + c] = static_cast<uint8_t>(byte);
         n_st++;

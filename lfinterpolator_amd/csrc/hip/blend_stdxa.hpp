@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
     const float bmax_acc = (c0 + nf * 0x1p-16f) * 0x1p-9f;
     const float base_acc = (0.5f - c0) * 0x1p-9f;
     const float chain_acc = nf * 0x1p-24f;
-    auto byte_of = [](const float s15) { return __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; };
+    auto byte_of15 = [](const float s15) { return __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; }; // the overflow path's scale (bytes as integers)
+    auto byte_of = [](const float s9) { return __builtin_bit_cast(uint32_t, s9 * 0x1p9f + 8388608.0f) & 0xffu; };     // the chain's: 2^-9 · sum
 
     // ---- the chain over one chunk for a queued sum = pixel of the wave (5 bits) | view << 5 (6 bits) | channel << 11, from buffers b -------
     auto chain = [&](const int b, const int kc, const uint32_t entry, float &s15) {
@@ -137,7 +138,8 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
             {
                 const uint32_t pair = j < 8 ? wlo[j >> 1] : whi[(j - 8) >> 1];
                 const float w = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(j & 1 ? pair >> 16 : pair)));
-                s = __builtin_fmaf(static_cast<float>(pbyte[j]), w, s); // addWeighted, src/kernels.cu:292-299
+                // the byte AS an fp16 subnormal (byte·2^-24): v_fma_mix_f32 widens both halves itself, no v_cvt_f32_ubyte per image (blend_stdx.hpp)
+                s = __builtin_fmaf(static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(pbyte[j]))), w, s); // addWeighted, src/kernels.cu:292-299
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -324,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
                             const float w = static_cast<float>(__builtin_bit_cast(_Float16, wrow[g]));
                             s = __builtin_fmaf(static_cast<float>(p), w, s);
                         }
-                        (plane0 + ((size_t)view * oplane_px + r) * 4)[c] = static_cast<uint8_t>(byte_of(s));
+                        (plane0 + ((size_t)view * oplane_px + r) * 4)[c] = static_cast<uint8_t>(byte_of15(s));
                     }
                 }
                 count += n;
