@@ -11,6 +11,7 @@ ctx = L.Context(0)
 ctx.set_grid(cols, rows, W, H); ctx.fill_synthetic(0x1F1F)
 ctx.set_params(L.build_params(cols, rows, W, H, traj, focus, 0.0, effect, aspect, V))
 ctx.set_output_layout(layout)
+ctx.prepare(method)  # the derived planar copy (with tuned phases) is built here, as in bench.py
 for _ in range(launches):
     ctx.render(method)
 ctx.sync()
