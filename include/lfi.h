@@ -242,7 +242,8 @@ typedef struct lfi_memory {
     size_t derived_bytes;   /* planar copy of the inputs: 3 bytes per pixel and image (+ padding) */
     size_t views_bytes;     /* output planes */
     size_t maps_bytes;      /* focus maps */
-    size_t workspace_bytes; /* focus-map workspace */
+    size_t workspace_bytes; /* focus-map workspace + (planar view layout) the RGBA scratch copy of the views that renders other than TEN_WM and
+                             * STD on more than 64 images go through, and the one-plane staging buffer of downloads */
     float derived_build_ms;
 } lfi_memory;
 int lfi_memory_info(lfi_ctx *ctx, lfi_memory *out);

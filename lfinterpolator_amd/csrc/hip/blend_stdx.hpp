@@ -72,7 +72,10 @@ __host__ __device__ constexpr int sx_buffer(const int j, const int sl)
     return (j & 1) ? 2 - v : v;
 }
 
-template <bool NT_STORE, int NCH>
+// PLANAR_OUT: the views are alpha-free byte planes [view][R,G,B][out_rows][views_pitch] (the library's planar layout, blend_p3.hpp) and are
+// written directly — eight bytes per lane, view and channel; a tile row of a plane is one 128-byte line — instead of RGBA planes (round 4: the
+// planar layout used to send STD through an RGBA scratch copy of all views and a conversion pass).
+template <bool NT_STORE, int NCH, bool PLANAR_OUT = false>
 __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const int tiles_x, const int n_tiles, const int reverse)
 {
     static_assert(NCH >= 2 && NCH <= 4, "two to four chunks of 64 images");
@@ -290,6 +293,23 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
     auto byte_of15 = [](const float s15) { return __builtin_bit_cast(uint32_t, s15 * 0x1p-15f + 8388608.0f) & 0xffu; }; // the spill path's scale
     auto byte_of = [](const float s9) { return __builtin_bit_cast(uint32_t, s9 * 0x1p9f + 8388608.0f) & 0xffu; };
 
+    // the byte of (view vw0 + v16, pixel px of the tile at row ty / column x0, channel ch) in the views
+    // = a wave-uniform 64-bit base (the tile's first byte in the wave's first plane) + a 32-bit offset (a wave's 16 views are at most 48 byte
+    // planes / 16 RGBA planes: below 4 GB, checked on the host)
+    const uint32_t plane_b = uint32_t(a.out_rows) * uint32_t(PLANAR_OUT ? a.views_pitch : 4 * a.width); // bytes of a byte plane / of an RGBA plane
+    auto out_base = [&](const int ty, const int x0) -> uint8_t * {
+        if constexpr(PLANAR_OUT)
+            return a.views + ((size_t)vw0 * 3 * a.out_rows + ty) * a.views_pitch + x0;
+        else
+            return a.views + (((size_t)vw0 * a.out_rows + ty) * a.width + x0) * 4;
+    };
+    auto out_off = [&](const uint32_t plane_bytes, const uint32_t v16, const uint32_t px, const uint32_t ch) -> uint32_t {
+        if constexpr(PLANAR_OUT)
+            return (3u * v16 + ch) * plane_bytes + px;
+        else
+            return v16 * plane_bytes + 4u * px + ch;
+    };
+
     // ---- the unit sequence of this workgroup: tiles t0, t0 + G, … (T of them), 2·NCH − 1 units each ------------------------------------
     // (The C units of a tile interleaved with the next tile's M units, so that no fetch is issued with two short units of lead, measured
     // SLOWER — 3.05 against 2.93 ms at config 5, profiles/r03_stdx_interleave_ab.txt: the second fetch is traffic, not latency.)
@@ -397,8 +417,11 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
 #pragma unroll
                 for(int b = 0; b < 8; b++)
                     px_ok |= (x0 + 8 * n + b < W) ? 7u << (3 * b) : 0u;
-                uint8_t *ubase = a.views + (((size_t)vw0 * a.out_rows + (LFI_SX_ABL == 6 ? 0 : ty)) * W + (LFI_SX_ABL == 6 ? 0 : x0)) * 4;
-                const size_t vstride = (size_t)a.out_rows * W * 4; // bytes between consecutive views
+                uint8_t *obase = out_base(LFI_SX_ABL == 6 ? 0 : ty, LFI_SX_ABL == 6 ? 0 : x0);
+                // opaque per tile: the compiler otherwise computes every store's per-lane offset once per kernel and keeps them all (24
+                // registers for the planar stores: spills)
+                uint32_t plane_e = plane_b;
+                asm volatile("" : "+s"(plane_e));
                 const bool full_x = x0 + 8 * n + 8 <= W;
 #pragma unroll
                 for(int i = 0; i < 4; i++)
@@ -406,6 +429,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                     if(i >= nvalid) // wave-uniform; otherwise lane (n = 0, kg = 0) is active below
                         continue;
                     uint32_t rgba[8];
+                    uint32_t pl[3][2]; // PLANAR_OUT: [channel][pixels 0–3 | 4–7] of this view, a byte per pixel
 #pragma unroll
                     for(int b = 0; b < 8; b++)
                     {
@@ -421,13 +445,41 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                             if constexpr(LFI_SX_ABL != 4)
                                 mask[i] |= __builtin_fabsf(dist) > inside ? 1u << (3 * b + ch) : 0u;
                             bits[ch] = __builtin_bit_cast(uint32_t, t);
+                            if constexpr(PLANAR_OUT)
+                            {
+                                // the rounded byte into position b & 3 of the channel's dword (one v_perm per sum)
+                                const uint32_t sel = (b & 3) == 0 ? 0x0c0c0c04u : ((b & 3) == 1 ? 0x0c0c0400u : ((b & 3) == 2 ? 0x0c040100u : 0x04020100u));
+                                pl[ch][b >> 2] = __builtin_amdgcn_perm(bits[ch], (b & 3) == 0 ? 0u : pl[ch][b >> 2], sel);
+                            }
                         }
-                        const uint32_t rg = __builtin_amdgcn_perm(bits[1], bits[0], 0x0c0c0400u); // [R, G, 0, 0]
-                        rgba[b] = __builtin_amdgcn_perm(bits[2], rg, 0x0d040100u);               // [R, G, B, 0xff]
+                        if constexpr(!PLANAR_OUT)
+                        {
+                            const uint32_t rg = __builtin_amdgcn_perm(bits[1], bits[0], 0x0c0c0400u); // [R, G, 0, 0]
+                            rgba[b] = __builtin_amdgcn_perm(bits[2], rg, 0x0d040100u);               // [R, G, B, 0xff]
+                        }
                     }
                     const bool view_ok = 4 * kg + i < nvalid;
                     mask[i] &= view_ok ? px_ok : 0u;
-                    uint32_t *out = reinterpret_cast<uint32_t *>(ubase + (size_t)(4 * kg + i) * vstride) + 8 * n;
+                    if constexpr(PLANAR_OUT)
+                    {
+                        // the pitch is a multiple of 128 ≥ W: a tile's row of a plane is a whole 128-byte line, also past the image's right edge
+                        if(view_ok && LFI_SX_ABL != 5)
+                        {
+#pragma unroll
+                            for(int ch = 0; ch < 3; ch++)
+                            {
+                                const u32x2 px8 = {pl[ch][0], pl[ch][1]};
+                                u32x2 *o8 = reinterpret_cast<u32x2 *>(obase + out_off(plane_e, uint32_t(4 * kg + i), uint32_t(8 * n), uint32_t(ch)));
+                                if constexpr(NT_STORE && LFI_SX_NT)
+                                    __builtin_nontemporal_store(px8, o8);
+                                else
+                                    *o8 = px8;
+                            }
+                        }
+                        st1 += 3;
+                        continue;
+                    }
+                    uint32_t *out = reinterpret_cast<uint32_t *>(obase + out_off(plane_e, uint32_t(4 * kg + i), uint32_t(8 * n), 0u));
                     if(full_x)
                     {
                         if(view_ok && LFI_SX_ABL != 5)
@@ -497,7 +549,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
                                 const float w = static_cast<float>(__builtin_bit_cast(_Float16, wrow[g]));
                                 s = __builtin_fmaf(static_cast<float>(p), w, s);
                             }
-                            (ubase + (size_t)(4 * kg + i_sel) * vstride)[(8 * n + int(b)) * 4 + int(ch)] = static_cast<uint8_t>(byte_of15(s));
+                            obase[out_off(plane_e, uint32_t(4 * kg + i_sel), uint32_t(8 * n) + b, ch)] = static_cast<uint8_t>(byte_of15(s));
                         }
                     }
                     count += __builtin_popcountll(m);
@@ -518,12 +570,11 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
             if constexpr(is_last_c && LFI_SX_ABL != 2)
             {
                 // the chain's bytes over the rounded ones (not counted in st1: an undercount is safe)
-                uint8_t *ubase = a.views + (((size_t)vw0 * a.out_rows + ty) * W + x0) * 4;
-                const size_t vstride = (size_t)a.out_rows * W * 4;
+                uint8_t *obase = out_base(ty, x0);
                 if(lane < queued)
-                    (ubase + (size_t)((entry0 >> 7) & 15u) * vstride)[(entry0 & 127u) * 4u + (entry0 >> 11)] = static_cast<uint8_t>(byte_of(s0));
+                    obase[out_off(plane_b, (entry0 >> 7) & 15u, entry0 & 127u, entry0 >> 11)] = static_cast<uint8_t>(byte_of(s0));
                 if(64 + lane < queued)
-                    (ubase + (size_t)((entry1 >> 7) & 15u) * vstride)[(entry1 & 127u) * 4u + (entry1 >> 11)] = static_cast<uint8_t>(byte_of(s1));
+                    obase[out_off(plane_b, (entry1 >> 7) & 15u, entry1 & 127u, entry1 >> 11)] = static_cast<uint8_t>(byte_of(s1));
             }
         }
 #if LFI_SX_TRACE

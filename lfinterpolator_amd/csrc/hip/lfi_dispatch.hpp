@@ -173,13 +173,22 @@ void launch_std_filtered_t(const lfi_ctx *c, const KernelArgs &a_in, bool all_fo
         const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
         const int nch = (a_in.k_pad + lfi::P3_KC - 1) / lfi::P3_KC;
         const int reverse = next_sweep_direction(c);
+        // planar views written directly: launch_blend has pointed a.views at the byte planes (stdx_writes_planar_views)
+        const bool planar_out = a_in.views == c->views && c->out_layout == LFI_LAYOUT_PLANAR_RGB;
         note_kernel(c, "blend_stdx<STD>");
         for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 64)
         {
             KernelArgs a = a_in;
             a.v0 = v0;
             a.v1 = std::min(v0 + 64, a_in.v1);
-#define LFI_SX_LAUNCH(N) hipLaunchKernelGGL((lfi::blend_stdx<true, N>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse)
+#define LFI_SX_LAUNCH(N)                                                                                                                        \
+    do                                                                                                                                          \
+    {                                                                                                                                           \
+        if(planar_out)                                                                                                                          \
+            hipLaunchKernelGGL((lfi::blend_stdx<true, N, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse);                   \
+        else                                                                                                                                    \
+            hipLaunchKernelGGL((lfi::blend_stdx<true, N>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, reverse);                         \
+    } while(0)
             switch(nch)
             {
                 case 2: LFI_SX_LAUNCH(2); break;
@@ -448,6 +457,15 @@ bool wants_p3(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
            !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) && kTenVariants[c->ten_variant].planar && a.k_pad <= 4 * lfi::P3_KC && planes_fit;
 }
 
+// planar view layout: does blend_stdx write the byte planes of this STD launch directly?  (fixed focus, 65–256 images, the default STD
+// variants, weights for which the band method's bounds hold, the planar input copy usable; the addressing of a plane row: 32-bit)
+bool stdx_writes_planar_views(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
+{
+    const bool planes_fit = (uint64_t)48 * (uint64_t)c->out_rows * (uint64_t)view_pitch(c) < (1ull << 32);
+    return c->out_layout == LFI_LAYOUT_PLANAR_RGB && method == LFI_METHOD_STD && c->std_variant <= 1 && a.k_pad > 64 && planes_fit &&
+           wants_planar(c, method, all_focus, a);
+}
+
 // Does a render with these arguments read the derived planar copy of the inputs?  ONE predicate for launch_blend's two branches,
 // lfi_prepare and lfi_benchmark (round 2: lfi_prepare tested wants_planar only and built nothing for launches that blend_p3 serves
 // beyond wants_planar's view limit — 256 views from 64 images — so the first render carried the build).
@@ -583,8 +601,11 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
         LFI_HIP(c, hipGetLastError());
         return LFI_OK;
     }
-    // every other render (STD, all-focus, debug modes, weights outside [0, 2)) goes through the RGBA kernels into a scratch copy of
-    // the views and is converted to byte planes afterwards
+    if(stdx_writes_planar_views(c, method, all_focus, a_in) && ensure_planar(c, tune_planar_now(c)))
+        // STD on more than 64 images: blend_stdx writes the byte planes itself (a.views are the context's planar views)
+        return launch_blend_rgba(c, method, all_focus, a_in);
+    // every other render (STD on up to 64 images, all-focus, debug modes, weights outside [0, 2)) goes through the RGBA kernels into a
+    // scratch copy of the views and is converted to byte planes afterwards
     const size_t need = rgba_out_plane_bytes(c) * c->views_n;
     if(c->rgba_scratch_bytes != need)
     {

@@ -858,7 +858,7 @@ int lfi_memory_info(lfi_ctx *ctx, lfi_memory *out)
     out->derived_bytes = ctx->planar ? ctx->planar_bytes : 0;
     out->views_bytes = ctx->views ? ctx->views_bytes : 0;
     out->maps_bytes = ctx->maps ? plane_bytes(ctx) * 2 : 0;
-    out->workspace_bytes = ctx->focus_ws_bytes;
+    out->workspace_bytes = ctx->focus_ws_bytes + ctx->rgba_scratch_bytes + ctx->dl_plane_bytes;
     out->derived_build_ms = ctx->derived_build_ms;
     return LFI_OK;
 }

@@ -673,10 +673,16 @@ def test_std_band_method_over_several_chunks(cols, rows, W, H, V, kind, gpu, ora
             ctx.render("STD", v0=v0, v1=v1)
             ctx.sync()
             assert (ctx.download_views(v0, v1) == want[v0:v1]).all(), (kind, "view range")
-            ctx.set_output_layout("planar")      # RGBA scratch + conversion
+            ctx.set_output_layout("planar")      # byte planes written by blend_stdx itself (round 4; before: RGBA scratch + conversion)
             ctx.render("STD")
             ctx.sync()
+            assert ctx.last_kernel_name() == "blend_stdx<STD>"
+            assert ctx.memory_info().workspace_bytes == 0, "no RGBA scratch copy of the views"
             assert (ctx.download_views() == want).all(), (kind, "planar layout")
+            ctx.render("STD")                    # the other sweep direction
+            ctx.render("STD", v0=v0, v1=v1)      # and a view range over it
+            ctx.sync()
+            assert (ctx.download_views() == want).all(), (kind, "planar layout, reverse sweep + view range")
         ctx.close()
 
 

@@ -19,7 +19,8 @@ for cfg in ((15, 15, 1920, 1080, 45, "0,0.5,1,0.5", 0.06, 2.276, 3.0), (15, 15, 
     ctx = L.Context(0)
     ctx.set_grid(cols, rows, W, H); ctx.fill_synthetic(0x1F1F)
     ctx.set_params(L.build_params(cols, rows, W, H, traj, focus, 0.0, effect, aspect, V))
-    for what, method, variant, layout in (("TEN_WM rgba", "TEN_WM", "auto", "rgba"), ("TEN_WM planar", "TEN_WM", "auto", "planar"), ("STD exact mfma", "STD", "wave_m2_nt", "rgba")):
+    for what, method, variant, layout in (("TEN_WM rgba", "TEN_WM", "auto", "rgba"), ("TEN_WM planar", "TEN_WM", "auto", "planar"), ("STD planar views", "STD", "auto", "planar"),
+                                          ("STD exact mfma", "STD", "wave_m2_nt", "rgba")):
         ctx.set_output_layout(layout)
         ctx.set_variant(method, variant)
         for _ in range(2): ctx.render(method)
