@@ -86,7 +86,10 @@ __device__ __forceinline__ void p3_for_each_chunk(F &&f)
 // 2: TWO waves per workgroup, 32 views each — the pixel operand of a block (LDS read + v_perm) is built once for two MFMAs, and the
 // kernel needs more than 256 registers (192 accumulators), which pins one wave to each SIMD: two workgroups per CU as before, each
 // wave alone on its SIMD.  For launches of several chunks, where the k-loop (not the DMA) sets the pace with four waves.
-template <bool NT_STORE, int NCH, int ABL = 0, int VG = 1, int MP = 1>
+// RGBA_OUT (round 4): the views are RGBA planes [view][out_rows][W] — the reference's layout, the library's default — written from the same
+// pipeline: a lane packs its eight pixels of a view into eight dwords (two v_perm per pixel, alpha = 255: uchar4{…, 255}, src/kernels.cu:393) and
+// stores them with two adjacent 16-byte stores (the halves of a 32-byte sector in neighbouring instructions: profiles/r04_notes.md §13).
+template <bool NT_STORE, int NCH, int ABL = 0, int VG = 1, int MP = 1, bool RGBA_OUT = false>
 __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes, const int reverse)
 {
     static_assert(VG == 1 || VG == 2, "16 or 32 views per wave");
@@ -346,6 +349,66 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
                            "+v"(h(17)), "+v"(h(18)), "+v"(h(19)), "+v"(h(20)), "+v"(h(21)), "+v"(h(22)), "+v"(h(23))
                          : "s"(k255), "s"(two));
 #undef h
+        }
+        if constexpr(RGBA_OUT)
+        {
+            // wave-uniform 64-bit base (the tile's first pixel in the wave's first view) + a 32-bit per-lane offset (16 RGBA planes < 4 GB:
+            // checked on the host); the plane size opaque per tile, so that the offsets are not computed once per kernel and kept in registers
+            uint8_t *ubase = a.views + (((size_t)vw * a.out_rows + ty) * a.width + x0) * 4;
+            uint32_t vplane = uint32_t(a.out_rows) * uint32_t(a.width) * 4u;
+            asm volatile("" : "+s"(vplane));
+            const bool full_x = x0 + 8 * n + 8 <= a.width;
+            int n_st = 0;
+#pragma unroll
+            for(int i = 0; i < 4; i++)
+            {
+                if(i >= nvalid) // wave-uniform; otherwise lane (n = 0, kg = 0) is active below
+                    continue;
+                uint32_t rgba[8];
+#pragma unroll
+                for(int b = 0; b < 8; b++)
+                {
+                    const int pr = b >> 1; // the pixel's half of its pair: the byte sits in the low byte of that half
+                    const uint32_t rg = __builtin_amdgcn_perm(hq[(i * 3 + 1) * 4 + pr], hq[(i * 3 + 0) * 4 + pr], (b & 1) ? 0x0c0c0602u : 0x0c0c0400u); // [R, G, 0, 0]
+                    rgba[b] = __builtin_amdgcn_perm(hq[(i * 3 + 2) * 4 + pr], rg, (b & 1) ? 0x0d060100u : 0x0d040100u);                            // [R, G, B, 0xff]
+                }
+                const bool view_ok = 4 * kg + i < nvalid;
+                uint32_t *out = reinterpret_cast<uint32_t *>(ubase + uint32_t(4 * kg + i) * vplane) + 8 * n;
+                if constexpr(ABL == 3)
+                {
+                    asm volatile("" ::"v"(rgba[0]), "v"(rgba[7]), "v"(out));
+                    continue;
+                }
+                if(full_x)
+                {
+                    if(view_ok)
+                    {
+                        const u32x4 lo4 = {rgba[0], rgba[1], rgba[2], rgba[3]}, hi4 = {rgba[4], rgba[5], rgba[6], rgba[7]};
+                        if constexpr(NT_STORE)
+                        {
+                            __builtin_nontemporal_store(lo4, reinterpret_cast<u32x4_a4 *>(out));
+                            __builtin_nontemporal_store(hi4, reinterpret_cast<u32x4_a4 *>(out + 4));
+                        }
+                        else
+                        {
+                            *reinterpret_cast<u32x4_a4 *>(out) = lo4;
+                            *reinterpret_cast<u32x4_a4 *>(out + 4) = hi4;
+                        }
+                    }
+                }
+                else if(view_ok) // the ragged right edge of the image: pixel by pixel
+                {
+#pragma unroll
+                    for(int b = 0; b < 8; b++)
+                        if(x0 + 8 * n + b < a.width)
+                            out[b] = rgba[b];
+                }
+                // counted for the vmcnt bookkeeping only where certainly issued (lane n = 0, kg = 0 takes the full-width branch); an
+                // undercount only makes the next waits stricter
+                if(x0 + 8 <= a.width)
+                    n_st += 2;
+            }
+            return n_st;
         }
         // 16 bytes per lane and store (round 3): the MFMA leaves a lane 8 pixels of four views; neighbouring lanes (n, n ^ 1) swap — the even
         // lane takes both lanes' pixels of view i0, the odd lane both lanes' pixels of view i0 + 1 (two DPP moves per channel) — so that one

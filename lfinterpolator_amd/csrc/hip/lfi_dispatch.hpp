@@ -91,6 +91,25 @@ void launch_planar(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     hipLaunchKernelGGL((lfi::blend_planar<2, NT_STORE>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes, RING3, next_sweep_direction(c));
 }
 
+// RGBA views (the reference's layout, the default) by blend_p3 with its RGBA epilogue (round 4) where it pays — fixed focus, the planar
+// copy of the inputs validated for this launch, TWO TO FOUR chunks of images (15×15 grids: −8 % at configs 3 and 5; with one chunk
+// blend_planar is as fast, and blend_persist faster for several view passes: profiles/r04_rgba_p3_ab.txt), a wave's 16 RGBA planes
+// addressable with 32 bits — else blend_planar / blend_persist.
+void launch_p3(const lfi_ctx *c, const KernelArgs &a_in, bool rgba_out = false);
+bool p3_rgba_planes_fit(const lfi_ctx *c)
+{
+    return (uint64_t)16 * (uint64_t)c->out_rows * (uint64_t)c->width * 4u < (1ull << 32);
+}
+void launch_p3_rgba(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
+{
+    if(!a.planar || all_focus || a.k_pad <= lfi::P3_KC || a.k_pad > 4 * lfi::P3_KC || !p3_rgba_planes_fit(c))
+    {
+        launch_planar<true>(c, a, all_focus);
+        return;
+    }
+    launch_p3(c, a, true);
+}
+
 // wave-private pipelines (blend_wave.hpp) where they apply — fixed focus, one K-chunk, one view pass — else blend_persist
 template <bool STD, int MT, bool NT_STORE>
 void launch_wave(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
@@ -244,6 +263,7 @@ void launch_std_vfma(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
 
 // first entry = default ("auto")
 const Variant kTenVariants[] = {
+    {"p3_rgba_nt", launch_p3_rgba, true, false, true, true},        // blend_p3 with the RGBA epilogue; blend_planar / blend_persist where it does not apply
     {"planar_m2_nt", launch_planar<true>, true, false, true, true}, // blend_persist where blend_planar does not apply
     {"persist_m2_nt", launch_persist<false, 2, true>, true, false, true},
     {"wave_m2_nt", launch_wave<false, 2, true>, true, false, true},
@@ -439,7 +459,11 @@ bool tune_planar_now(lfi_ctx *c)
 // assembly repeats per view pass).
 bool wants_planar(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
 {
-    if(all_focus || a.prequant || !c->weights_scalable || (a.v1 - a.v0 > std::max(c->n, 64) && !c->inputs_released))
+    if(all_focus || a.prequant || !c->weights_scalable)
+        return false;
+    // (TEN_WM only: STD's alternative there is the exact-fp32 kernel — 256 views from 64 images at 4K: 7.2 ms against 3.4 with the band method
+    // on the planar copy, profiles/r04_rgba_p3_ab.txt)
+    if(method == LFI_METHOD_TEN_WM && a.v1 - a.v0 > std::max(c->n, 64) && !c->inputs_released)
         return false;
     if(method == LFI_METHOD_TEN_WM)
         return kTenVariants[c->ten_variant].planar && !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH);
@@ -476,7 +500,7 @@ bool wants_derived_copy(const lfi_ctx *c, int method, int all_focus, const Kerne
     return (c->out_layout == LFI_LAYOUT_PLANAR_RGB && wants_p3(c, method, all_focus, a)) || wants_planar(c, method, all_focus, a);
 }
 
-void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
+void launch_p3(const lfi_ctx *c, const KernelArgs &a_in, bool rgba_out)
 {
     const int tiles_x = (a_in.width + lfi::P3_TPX - 1) / lfi::P3_TPX;
     const int n_tiles = tiles_x * a_in.out_rows;
@@ -487,7 +511,7 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
     const dim3 grid(std::min(n_tiles, 2 * cu_count_of(c))), block(256);
 #endif
     const int nch = (a_in.k_pad + lfi::P3_KC - 1) / lfi::P3_KC;
-    note_kernel(c, "blend_p3<TEN_WM>");
+    note_kernel(c, rgba_out ? "blend_p3<TEN_WM,rgba>" : "blend_p3<TEN_WM>");
 #ifdef LFI_MEASUREMENT_BUILD
     // measurement builds only (make HIPFLAGS+=-DLFI_MEASUREMENT_BUILD, tools/p3_ablate.py): where does a unit's time go?  The ablated
     // kernels write garbage by construction, so the production library does not contain them and reads no such environment variable.
@@ -542,6 +566,7 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
                 continue;
             }
 #endif
+            // (one chunk of images: the planar views' epilogue only — launch_p3_rgba keeps blend_planar / blend_persist there)
             if(passes == 1)
                 hipLaunchKernelGGL((lfi::blend_p3<true, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, 1, dir);
             else
@@ -556,7 +581,13 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in)
         a.v0 = v0;
         a.v1 = std::min(v0 + 64, a_in.v1);
 #define LFI_P3_LAUNCH(N)                                                                                                                        \
-    hipLaunchKernelGGL((lfi::blend_p3<true, N, 0, 2>), grid, block2, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse)
+    do                                                                                                                                          \
+    {                                                                                                                                           \
+        if(rgba_out)                                                                                                                            \
+            hipLaunchKernelGGL((lfi::blend_p3<true, N, 0, 2, 1, true>), grid, block2, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse);        \
+        else                                                                                                                                    \
+            hipLaunchKernelGGL((lfi::blend_p3<true, N, 0, 2>), grid, block2, 0, stream_of(c), a, tiles_x, n_tiles, 1, reverse);                 \
+    } while(0)
 #ifdef LFI_MEASUREMENT_BUILD
         if(vg_env == 1)
         {

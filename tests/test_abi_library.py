@@ -113,7 +113,8 @@ def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_pat
     assert sum("blend_stdxI" in k for k in pipelined) == 6    # fixed focus: two, three and four chunks of images, RGBA and planar views
     assert sum("blend_stdxaI" in k for k in pipelined) == 4   # all-focus: one to four chunks
     assert len(pipelined) >= 10, sorted(kernels)
-    p3_name = re.compile(r"blend_p3ILb1ELi(\d)ELi(\d)ELi(\d)ELi(\d)EEEv")  # <true, chunks, ablation, view groups per wave, view passes>
+    # <true, chunks, ablation, view groups per wave, view passes, RGBA epilogue>
+    p3_name = re.compile(r"blend_p3ILb1ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])EEEv")
     n_two_groups = 0
     for k in pipelined:
         assert kernels[k][".private_segment_fixed_size"] == 0 and kernels[k][".vgpr_spill_count"] == 0, (k, kernels[k])
@@ -136,7 +137,14 @@ def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_pat
             body[cur] = []
         elif cur:
             body[cur].append(line)
-    shipped = [k for k in body if p3_name.search(k) and p3_name.search(k).group(2) == "0"]
+    rgba_out = [k for k in body if p3_name.search(k) and p3_name.search(k).group(2) == "0" and p3_name.search(k).group(5) == "1"]
+    assert len(rgba_out) >= 3, sorted(body)  # the RGBA epilogue (round 4): two to four chunks of images at least
+    for k in rgba_out:
+        text = "\n".join(body[k])
+        n_st16 = len(re.findall(r"global_store_dwordx4", text))
+        assert n_st16 >= 8 and n_st16 % 8 == 0, (k, n_st16)  # two adjacent 16-byte stores per view (the ragged right edge: dword stores)
+        assert "scratch_" not in text and "buffer_store" not in text and "buffer_load" not in text, k
+    shipped = [k for k in body if p3_name.search(k) and p3_name.search(k).group(2) == "0" and p3_name.search(k).group(5) == "0"]
     assert len(shipped) >= 5, sorted(body)   # one chunk: one pass / up to four; two to four chunks: two waves of 32 views
     assert sum(p3_name.search(k).group(4) == "4" for k in shipped) == 1     # up to four view passes: one chunk of images, 16 views per wave
     for k in shipped:
