@@ -68,6 +68,8 @@ template <int NCH>
 __host__ __device__ constexpr int sx_buffer(const int j, const int sl)
 {
     constexpr int t2[3] = {0, 1, 0}, t3[5] = {0, 1, 2, 1, 0}, t4[7] = {0, 1, 2, 0, 2, 1, 0};
+    if(NCH == 1)
+        return j % 3; // one unit per tile (MC(0): k-loop, band test, the whole chain from the buffer it just used): a plain ring of three
     const int v = NCH == 2 ? t2[sl] : (NCH == 3 ? t3[sl] : t4[sl]);
     return (j & 1) ? 2 - v : v;
 }
@@ -78,7 +80,7 @@ __host__ __device__ constexpr int sx_buffer(const int j, const int sl)
 template <bool NT_STORE, int NCH, bool PLANAR_OUT = false>
 __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const int tiles_x, const int n_tiles, const int reverse)
 {
-    static_assert(NCH >= 2 && NCH <= 4, "two to four chunks of 64 images");
+    static_assert(NCH >= 1 && NCH <= 4, "one to four chunks of 64 images");
     constexpr int NW = 4, OPW = 2;
     constexpr int NU = 2 * NCH - 1; // unit slots per iteration
     constexpr int QUEUE_OFF = 3 * P3_BUF_B + LFI_MAX_IMAGES * 8;

@@ -183,7 +183,12 @@ void launch_std_filtered_t(const lfi_ctx *c, const KernelArgs &a_in, bool all_fo
         launch_wave<true, 2, true>(c, a_in, all_focus);
         return;
     }
-    if(a_in.k_pad > 64)
+    // planar views written directly (launch_blend has pointed a.views at the byte planes: stdx_writes_planar_views): blend_stdx also for ONE
+    // chunk of images — blend_planar<STDF> would go through an RGBA scratch copy of all views and a conversion pass (config 2: 0.45 ms
+    // against 0.23).  With RGBA views blend_planar<STDF> stays: as fast at config 2, 15 % faster for one rank of config 4
+    // (profiles/r04_rgba_p3_ab.txt).
+    const bool planar_views = a_in.views == c->views && c->out_layout == LFI_LAYOUT_PLANAR_RGB;
+    if(a_in.k_pad > 64 || planar_views)
     {
         // more than one chunk of images (15×15 grids): blend_stdx — the band method with the chain's bytes fetched a second time;
         // one launch per 64 views (the accumulators of a wave hold 16 views)
@@ -193,7 +198,7 @@ void launch_std_filtered_t(const lfi_ctx *c, const KernelArgs &a_in, bool all_fo
         const int nch = (a_in.k_pad + lfi::P3_KC - 1) / lfi::P3_KC;
         const int reverse = next_sweep_direction(c);
         // planar views written directly: launch_blend has pointed a.views at the byte planes (stdx_writes_planar_views)
-        const bool planar_out = a_in.views == c->views && c->out_layout == LFI_LAYOUT_PLANAR_RGB;
+        const bool planar_out = planar_views;
         note_kernel(c, "blend_stdx<STD>");
         for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 64)
         {
@@ -210,6 +215,7 @@ void launch_std_filtered_t(const lfi_ctx *c, const KernelArgs &a_in, bool all_fo
     } while(0)
             switch(nch)
             {
+                case 1: LFI_SX_LAUNCH(1); break; // (planar views only)
                 case 2: LFI_SX_LAUNCH(2); break;
                 case 3: LFI_SX_LAUNCH(3); break;
                 default: LFI_SX_LAUNCH(4); break;
@@ -481,12 +487,12 @@ bool wants_p3(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
            !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) && kTenVariants[c->ten_variant].planar && a.k_pad <= 4 * lfi::P3_KC && planes_fit;
 }
 
-// planar view layout: does blend_stdx write the byte planes of this STD launch directly?  (fixed focus, 65–256 images, the default STD
+// planar view layout: does blend_stdx write the byte planes of this STD launch directly?  (fixed focus, up to 256 images, the default STD
 // variants, weights for which the band method's bounds hold, the planar input copy usable; the addressing of a plane row: 32-bit)
 bool stdx_writes_planar_views(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
 {
     const bool planes_fit = (uint64_t)48 * (uint64_t)c->out_rows * (uint64_t)view_pitch(c) < (1ull << 32);
-    return c->out_layout == LFI_LAYOUT_PLANAR_RGB && method == LFI_METHOD_STD && c->std_variant <= 1 && a.k_pad > 64 && planes_fit &&
+    return c->out_layout == LFI_LAYOUT_PLANAR_RGB && method == LFI_METHOD_STD && c->std_variant <= 1 && planes_fit &&
            wants_planar(c, method, all_focus, a);
 }
 
@@ -633,9 +639,9 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
         return LFI_OK;
     }
     if(stdx_writes_planar_views(c, method, all_focus, a_in) && ensure_planar(c, tune_planar_now(c)))
-        // STD on more than 64 images: blend_stdx writes the byte planes itself (a.views are the context's planar views)
+        // fixed-focus STD: blend_stdx writes the byte planes itself (a.views are the context's planar views)
         return launch_blend_rgba(c, method, all_focus, a_in);
-    // every other render (STD on up to 64 images, all-focus, debug modes, weights outside [0, 2)) goes through the RGBA kernels into a
+    // every other render (all-focus, debug modes, weights outside [0, 2) or summing above 2) goes through the RGBA kernels into a
     // scratch copy of the views and is converted to byte planes afterwards
     const size_t need = rgba_out_plane_bytes(c) * c->views_n;
     if(c->rgba_scratch_bytes != need)

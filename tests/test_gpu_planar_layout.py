@@ -45,9 +45,10 @@ def test_golden_fixtures_planar_layout(case, gpu):
     assert np.abs(out.astype(int) - g["ten_m16"].astype(int)).max() <= TEN_TOL_LSB
     assert (out[..., 3] == 255).all()
     assert (out != g["ten_exact"]).mean() < 1e-3
-    # the renders blend_p3 does not serve go through the RGBA kernels and a conversion: same bytes as ever
+    # STD: blend_stdx writes the byte planes itself (round 4); all-focus renders go through the RGBA kernels and a conversion: same bytes as ever
     ctx.render("STD")
     ctx.sync()
+    assert ctx.last_kernel_name() == "blend_stdx<STD>"
     assert (ctx.download_views() == g["std"]).all()
     ctx.focus_map()
     ctx.render("STD", all_focus=True)
