@@ -110,7 +110,7 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
     import numpy as np
     out = {}
 
-    def entry(cfg, ms, views, kernel, note=None, flops_bound=None, n_images=None, in_bytes_extra=0.0):
+    def entry(cfg, ms, views, kernel, note=None, flops_bound=None, n_images=None, in_bytes_extra=0.0, out_bpp=None):
         n = n_images if n_images is not None else cfg["cols"] * cfg["rows"]
         ba = b_alg(cfg["W"], cfg["H"], n, cfg["H"], views) + in_bytes_extra
         fa = 6.0 * n * views * cfg["W"] * cfg["H"]
@@ -118,7 +118,8 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         # read the alpha-free planar copy, 3 B per pixel and view for blend_p3's planar views, 4 B on RGBA sides — ÷ time ÷ 8 TB/s; the
         # fraction on SURVEY.md's 4·W·H·(N + V) is kept as `frac_algorithmic` (round 3 printed that one as `frac` here: ADVICE r3)
         in_bpp = 3 if any(k in kernel for k in ("blend_p3", "blend_planar", "blend_stdx<")) else 4
-        out_bpp = 3 if "blend_p3" in kernel else 4
+        if out_bpp is None:  # blend_p3 writes planar views (3 B) or, named so, RGBA views; blend_stdx writes either: its callers say which
+            out_bpp = 3 if ("blend_p3" in kernel and ",rgba>" not in kernel) else 4
         bm = 1.0 * cfg["W"] * cfg["H"] * (in_bpp * n + out_bpp * views) + in_bytes_extra
         e = {"workload": f"{cfg['cols']}x{cfg['rows']} LF @{cfg['W']}x{cfg['H']}, {views} views", "kernel": kernel, "ms": ms,
              "views_per_s": views / ms * 1e3, "algorithmic_bytes": ba, "moved_bytes": bm, "hbm_gbs": bm / ms / 1e6, "frac": bm / ms / 1e6 / HBM_PEAK_GBS,
@@ -183,6 +184,9 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters, prepare=("TEN_WM",))
         out["config3"] = entry(c3, ms, 45, ctx.last_kernel_name())
         ctx.set_output_layout("rgba")
+        if layout != "rgba":
+            ms = timed(ctx, lambda: ctx.render("TEN_WM"), iters, prepare=("TEN_WM",))
+            out["config3_rgba_views"] = entry(c3, ms, 45, ctx.last_kernel_name(), "views stored as RGBA planes (the reference's layout)")
         ms = timed(ctx, lambda: ctx.render("STD"), max(2, iters // 2), prepare=("STD",))
         out["config3_std"] = entry(c3, ms, 45, ctx.last_kernel_name(), "bit-exact STD on a 15x15 grid (four chunks of images): fp16 MFMA sums + the exact chain inside the rounding band")
         ctx.close()
@@ -228,7 +232,13 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
             ctx.set_output_layout(layout)
         ms = timed(ctx, lambda: ctx.render("TEN_WM"), max(2, iters // 2), prepare=("TEN_WM",))
         out["config5_fixed_focus"] = entry(c5, ms, 64, ctx.last_kernel_name())
+        if layout != "rgba":
+            ms = timed(ctx, lambda: ctx.render("STD"), max(2, iters // 4), warm=1, prepare=("STD",))
+            out["config5_fixed_focus_std_planar_views"] = entry(c5, ms, 64, ctx.last_kernel_name(), "bit-exact STD into the planar views (written by the kernel itself)", out_bpp=3)
         ctx.set_output_layout("rgba")
+        if layout != "rgba":
+            ms = timed(ctx, lambda: ctx.render("TEN_WM"), max(2, iters // 2), prepare=("TEN_WM",))
+            out["config5_fixed_focus_rgba_views"] = entry(c5, ms, 64, ctx.last_kernel_name(), "views stored as RGBA planes (the reference's layout)")
         # BASELINE config 5's comparison, fixed focus: bit-exact STD by the default kernel and by the NON-TENSOR wavefront kernel
         # (blend_std_vfma, the analogue of Standard::process, src/kernels.cu:312-342)
         ms = timed(ctx, lambda: ctx.render("STD"), max(2, iters // 4), warm=1, prepare=("STD",))
