@@ -59,6 +59,9 @@ __host__ __device__ constexpr int p3_octet_off(int o)
 #ifndef LFI_P3_TRACE
 #define LFI_P3_TRACE 0
 #endif
+#ifndef LFI_P3_INTERLEAVE
+#define LFI_P3_INTERLEAVE 1
+#endif
 #if LFI_P3_TRACE
 __device__ unsigned long long lfi_p3_trace_buf[1024 * 8];
 #define LFI_P3_STAMP(var) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
@@ -220,19 +223,17 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
             }
         }
     };
-    // returns the number of DMA instructions issued by this wave (wave-uniform)
-    auto issue = [&](const TileCursor &tc, const int chunk, const int buf, const Pieces &pc) {
+    // one octet of images (three LDS-DMA instructions) of a unit's fetch; returns the number of DMA instructions issued by this wave (wave-uniform)
+    auto issue_piece = [&](const TileCursor &tc, const int chunk, const int buf, const Pieces &pc, const int o2) {
         const int y = a.out_y0 + tc.ty;
         const int x0 = tc.tx * P3_TPX;
         const int kc = min(P3_KC, a.k_pad - P3_KC * chunk);
         const uint32_t dst = lds_base + uint32_t(buf) * P3_BUF_B;
         int count = 0;
-#pragma unroll
-        for(int o2 = 0; o2 < OPW; o2++)
         {
             const int octet = wave + NW * o2;
             if(8 * octet >= kc)
-                continue; // wave-uniform: the chunk is shorter (its length is a multiple of 16)
+                return 0; // wave-uniform: the chunk is shorter (its length is a multiple of 16)
             // the run starts at pixel x0 + ox; the padding exceeds every offset
             const int sy = clampi(y + pc.oy[o2], 0, H - 1) - a.in_y0; // clamp in the full image, then index the held rows
             const int start = x0 + pc.ox[o2] + a.planar_padx; // any byte of the plane row (byte-aligned LDS-DMA: blend_planar.hpp)
@@ -251,6 +252,13 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
         }
         return count;
     };
+    auto issue = [&](const TileCursor &tc, const int chunk, const int buf, const Pieces &pc) {
+        int count = 0;
+#pragma unroll
+        for(int o2 = 0; o2 < OPW; o2++)
+            count += issue_piece(tc, chunk, buf, pc, o2);
+        return count;
+    };
 
     f32x4 acc[VG][8][3]; // [view group][block = pixel 8n + blk][channel]: views 16·group + 4kg + i
     auto clear_acc = [&] {
@@ -267,7 +275,7 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
     // k-loop of one unit from buffer `buf`: wk = the chunk's two weight fragments
     const uint32_t lane_px = uint32_t(1024 * kg + 128 * ((kg + 1) >> 1) + 8 * n); // p3_octet_off(kg) + this lane's 8 pixels
     // `fresh` (one-chunk launches): the first k-step takes a zero C operand, so the accumulators are never cleared
-    auto compute = [&](const half8 (&wk)[VG][2], const int buf, const int kc, auto fresh_tag) {
+    auto compute = [&](const half8 (&wk)[VG][2], const int buf, const int kc, auto fresh_tag, auto &&mid) {
         constexpr bool fresh = decltype(fresh_tag)::value;
         if constexpr(ABL == 1)
             return;
@@ -312,8 +320,13 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
                     acc[vg][b][ch] =
                         __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[vg][ks], __builtin_bit_cast(half8, bf), (ks == 0 && fresh) ? zero4 : acc[vg][b][ch], 0, 0, 0);
             }
+            // behind the group's MFMAs (they run in the matrix pipe while the wave issues this): a slice of the next fetch's issue work
+            __builtin_amdgcn_sched_barrier(0);
+            mid(grp);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto no_mid = [](const int) {};
 
     // epilogue of tile t: quantise (acc = S·2^-9), pack eight pixels per (view, channel), store; returns the number of store
     // instructions issued (wave-uniform)
@@ -526,13 +539,28 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
 #endif
         const bool have2 = have1 && it < n_tiles;
         int nd2 = 0;
-        if(have2)
+        // LFI_P3_INTERLEAVE (several chunks: one wave per SIMD, nothing else to fill its issue slots): the fetch is issued in slices BEHIND the
+        // groups of the k-loop, whose MFMAs keep the matrix pipe busy meanwhile, instead of in front of it
+        constexpr bool interleave = LFI_P3_INTERLEAVE && NCH > 1;
+        const int buf_next = buf == 0 ? 2 : buf - 1; // (buf + 2) % 3: the buffer the previous unit used
+        if(have2 && !interleave)
         {
-            nd2 = issue(itc, ic, buf == 0 ? 2 : buf - 1, pc); // (buf + 2) % 3: the buffer the previous unit used
+            nd2 = issue(itc, ic, buf_next, pc);
             advance_issue();
             if constexpr(NCH > 1)
                 pc = lookup(ic); // for the unit after that: off the critical path of the next barrier
         }
+        auto fetch_slice = [&](const int grp) { // slices 0 … OPW − 1: an octet each; slice OPW: the cursor and the next lookup
+            if(!have2)
+                return;
+            if(grp < OPW)
+                nd2 += issue_piece(itc, ic, buf_next, pc, grp);
+            else if(grp == OPW)
+            {
+                advance_issue();
+                pc = lookup(ic);
+            }
+        };
         const int kc = min(P3_KC, a.k_pad - P3_KC * cc);
 #if LFI_P3_TRACE
         LFI_P3_STAMP(tC);
@@ -561,7 +589,7 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
                         wk[vg][0] = pass == 0 ? wreg[vg][0] : wmore[pass > 0 ? pass - 1 : 0][vg][0];
                         wk[vg][1] = pass == 0 ? wreg[vg][1] : wmore[pass > 0 ? pass - 1 : 0][vg][1];
                     }
-                    compute(wk, buf, kc, std::true_type{});
+                    compute(wk, buf, kc, std::true_type{}, no_mid);
 #if LFI_P3_TRACE
                     LFI_P3_STAMP(tD);
                     tr_kloop += tD - tC;
@@ -596,6 +624,13 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
         else
         {
             const int nvalid = __builtin_amdgcn_readfirstlane(min(a.v1 - vw0, 16 * VG)); // ≤ 0: this wave only helps with the DMA
+            if constexpr(interleave)
+                if(nvalid <= 0)
+                {
+#pragma unroll
+                    for(int g = 0; g <= OPW; g++)
+                        fetch_slice(g);
+                }
             if(nvalid > 0)
             {
                 half8 wk[VG][2];
@@ -605,7 +640,17 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
                     wk[vg][0] = wreg[vg][2 * cc];
                     wk[vg][1] = wreg[vg][2 * cc + 1];
                 }
-                compute(wk, buf, kc, std::integral_constant<bool, cc == 0>{}); // chunk 0 starts from a zero C operand: no clears
+                if constexpr(interleave)
+                {
+                    compute(wk, buf, kc, std::integral_constant<bool, cc == 0>{}, fetch_slice);
+                    const int done = kc > 32 ? 6 : 3; // the groups the k-loop had: the slices it did not reach
+#pragma unroll
+                    for(int g = 3; g <= OPW; g++)
+                        if(g >= done)
+                            fetch_slice(g);
+                }
+                else
+                    compute(wk, buf, kc, std::integral_constant<bool, cc == 0>{}, no_mid); // chunk 0 starts from a zero C operand: no clears
 #if LFI_P3_TRACE
                 LFI_P3_STAMP(tD);
                 tr_kloop += tD - tC;
