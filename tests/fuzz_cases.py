@@ -55,7 +55,7 @@ def fuzz_blend(L, oc, n_cases: int, seed: int, log=None) -> list:
             if d > TEN_TOL_LSB or not (ctx.download_views() == full).all():
                 bad.append(dict(case, what="TEN_WM", variant=var, lsb=d, v0=v0, v1=v1))
         # the planar view layout: TEN_WM within one LSB of the oracle and byte-identical to the RGBA layout's default kernel, view ranges
-        # included; STD bit-exact through the scratch conversion
+        # included; STD bit-exact (round 4: blend_stdx writes the byte planes itself, one to four chunks of images), a view range over it too
         ctx.set_variant("TEN_WM", "auto")
         ctx.set_variant("STD", "auto")
         ctx.render("TEN_WM")
@@ -70,6 +70,7 @@ def fuzz_blend(L, oc, n_cases: int, seed: int, log=None) -> list:
         ctx.sync()
         part = ctx.download_views()
         ctx.render("STD")
+        ctx.render("STD", v0=v0, v1=v1)
         ctx.sync()
         d = int(np.abs(got.astype(int) - want_ten.astype(int)).max())
         if d > TEN_TOL_LSB or not (got == want_rgba).all() or not (part == got).all() or not (ctx.download_views() == want_std).all():
