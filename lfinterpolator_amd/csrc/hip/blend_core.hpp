@@ -268,4 +268,67 @@ __device__ __forceinline__ int store_tile(const KernelArgs &a, f32x16 (&acc)[MT]
     return n_st;
 }
 
+// The same tile into the PLANAR view layout (alpha-free byte planes [view][R,G,B][out_rows][views_pitch], blend_p3.hpp) — round 4, for the
+// all-focus TEN_WM render: a lane holds the RGBA dword of ONE pixel (r) per view; the four lanes of a quad (four neighbouring pixels) transpose
+// their 4 × 4 bytes with two DPP moves and two v_perm per view — lane 0 of the quad ends up with the four R bytes, lane 2 with G, lane 1 with
+// B — and store one dword each: a wave writes a whole 32-byte sector per view and channel.  The pitch is a multiple of 128 ≥ W, so pixels
+// past the right edge land in the row's padding.  Returns the number of store instructions issued (wave-uniform).
+template <bool STD, int MT, bool NT_STORE, bool CLEAR>
+__device__ __forceinline__ int store_tile_planar(const KernelArgs &a, f32x16 (&acc)[MT][3], const int vbase, const int y, const int xw, const int r,
+                                                 const int h)
+{
+    int n_st = 0;
+    uint32_t plane_b = uint32_t(a.out_rows) * uint32_t(a.views_pitch); // bytes of a byte plane; opaque per tile (no offsets kept across tiles)
+    asm volatile("" : "+s"(plane_b));
+    const uint32_t sel1 = (r & 1) ? 0x03070206u : 0x05010400u; // odd lane: [Y.b2, X.b2, Y.b3, X.b3], even: [X.b0, Y.b0, X.b1, Y.b1]
+    const uint32_t sel2 = (r & 2) ? 0x03020706u : 0x05040100u; // upper pair: [Z.b2, Z.b3, P.b2, P.b3], lower: [P.b0, P.b1, Z.b0, Z.b1]
+    const int role = (r & 3) == 0 ? 0 : ((r & 3) == 2 ? 1 : ((r & 3) == 1 ? 2 : 3)); // the plane this lane stores: R, G, B, none
+#pragma unroll
+    for(int m = 0; m < MT; m++)
+    {
+        const int view_m = vbase + m * 32;
+        const int nvalid = min(a.v1 - view_m, 32); // views of this M-tile inside the launch's range
+        if(nvalid > 0 && xw < a.width)
+        {
+            uint32_t rgba[16];
+            if constexpr(STD)
+                quantize_tile_rn(acc[m][0], acc[m][1], acc[m][2], rgba);
+            else
+                quantize_tile_packed(acc[m][0], acc[m][1], acc[m][2], rgba);
+            uint8_t *ubase = a.views + ((size_t)view_m * 3 * a.out_rows + y) * a.views_pitch + xw;
+            const uint32_t lane_off = (uint32_t(12 * h) + uint32_t(role)) * plane_b + uint32_t(r & ~3);
+#pragma unroll
+            for(int e = 0; e < 16; e++)
+            {
+                const int vrow = (e & 3) + 8 * (e >> 2); // + 4h in lane_off
+                const uint32_t swapped = uint32_t(__builtin_amdgcn_mov_dpp(int(rgba[e]), 0xB1, 0xf, 0xf, false)); // quad_perm [1, 0, 3, 2]
+                const uint32_t pair = __builtin_amdgcn_perm(swapped, rgba[e], sel1);
+                const uint32_t other = uint32_t(__builtin_amdgcn_mov_dpp(int(pair), 0x4E, 0xf, 0xf, false)); // quad_perm [2, 3, 0, 1]
+                const uint32_t px4 = __builtin_amdgcn_perm(other, pair, sel2);
+                if(vrow < nvalid) // wave-uniform; lane (r = 0, h = 0) is then always active, so the store is issued
+                {
+                    n_st++;
+                    uint32_t *out = reinterpret_cast<uint32_t *>(ubase + uint32_t(3 * vrow) * plane_b + lane_off);
+                    if(role < 3 && vrow + 4 * h < nvalid)
+                    {
+                        if constexpr(NT_STORE)
+                            __builtin_nontemporal_store(px4, out);
+                        else
+                            *out = px4;
+                    }
+                }
+            }
+        }
+        if constexpr(CLEAR)
+        {
+#pragma unroll
+            for(int c = 0; c < 3; c++)
+#pragma unroll
+                for(int e = 0; e < 16; e++)
+                    acc[m][c][e] = 0.0f;
+        }
+    }
+    return n_st;
+}
+
 } // namespace lfi

@@ -68,7 +68,8 @@ struct PersistCfg
 
 // STD = false: TEN_WM (fp16 MFMA, packed truncating epilogue, weights ×2^15);  STD = true: the exact-fp32 path of
 // Kernels::Standard::process (reference src/kernels.cu:289-343) on v_mfma_f32_32x32x2_f32 — see blend_std.hpp — in the same pipeline.
-template <bool STD, int MT, bool ALLFOCUS, bool NT_STORE, int KC_ = 64, int WGS = 2>
+// PLANAR_VIEWS: the views are the planar layout's byte planes (store_tile_planar, blend_core.hpp) instead of RGBA planes
+template <bool STD, int MT, bool ALLFOCUS, bool NT_STORE, int KC_ = 64, int WGS = 2, bool PLANAR_VIEWS = false>
 __global__ void __launch_bounds__(256, WGS)
     blend_persist(const KernelArgs a, const int tiles_x, const int n_tiles, const int view_passes)
 {
@@ -333,7 +334,10 @@ __global__ void __launch_bounds__(256, WGS)
         {
             const int y = t / tiles_x; // row inside the output window
             const int xw = (t - y * tiles_x) * TPX + wave * 32;
-            prev_stores = store_tile<STD, MT, NT_STORE, true>(a, acc, a.v0 + pass * VPP, y, xw, r, h, oplane_px);
+            if constexpr(PLANAR_VIEWS)
+                prev_stores = store_tile_planar<STD, MT, NT_STORE, true>(a, acc, a.v0 + pass * VPP, y, xw, r, h);
+            else
+                prev_stores = store_tile<STD, MT, NT_STORE, true>(a, acc, a.v0 + pass * VPP, y, xw, r, h, oplane_px);
         }
 
         if(!have_next)

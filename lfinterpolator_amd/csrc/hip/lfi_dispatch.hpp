@@ -67,6 +67,13 @@ void launch_persist(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     // persistent: WGS workgroups per CU (2 x 80 KB of LDS at KC = 64), each walks tiles j, j+G, j+2G ...
     const dim3 grid(std::min(n_tiles, WGS * cu_count_of(c))), block(256);
     note_kernel(c, STD ? (all_focus ? "blend_persist<STD,allfocus>" : "blend_persist<STD>") : (all_focus ? "blend_persist<TEN_WM,allfocus>" : "blend_persist<TEN_WM>"));
+    if constexpr(!STD && MT == 2 && KC == 64 && WGS == 2)
+        if(all_focus && a.views == c->views && c->out_layout == LFI_LAYOUT_PLANAR_RGB)
+        {
+            // the planar layout's byte planes written by the kernel itself (launch_blend: persist_writes_planar_views)
+            hipLaunchKernelGGL((lfi::blend_persist<false, 2, true, NT_STORE, 64, 2, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
+            return;
+        }
     if(all_focus)
         hipLaunchKernelGGL((lfi::blend_persist<STD, MT, true, NT_STORE, KC, WGS>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles, passes);
     else
@@ -496,6 +503,14 @@ bool stdx_writes_planar_views(const lfi_ctx *c, int method, int all_focus, const
            wants_planar(c, method, all_focus, a);
 }
 
+// planar view layout: does blend_persist write the byte planes of this all-focus TEN_WM render directly?  (the default variants — both end in
+// blend_persist for all-focus renders —, weights in [0, 2) for the packed epilogue, no debug modes)
+bool persist_writes_planar_views(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
+{
+    return c->out_layout == LFI_LAYOUT_PLANAR_RGB && method == LFI_METHOD_TEN_WM && all_focus && c->ten_variant <= 1 && c->weights_scalable && !a.prequant &&
+           !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH);
+}
+
 // Does a render with these arguments read the derived planar copy of the inputs?  ONE predicate for launch_blend's two branches,
 // lfi_prepare and lfi_benchmark (round 2: lfi_prepare tested wants_planar only and built nothing for launches that blend_p3 serves
 // beyond wants_planar's view limit — 256 views from 64 images — so the first render carried the build).
@@ -641,7 +656,10 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
     if(stdx_writes_planar_views(c, method, all_focus, a_in) && ensure_planar(c, tune_planar_now(c)))
         // fixed-focus STD: blend_stdx writes the byte planes itself (a.views are the context's planar views)
         return launch_blend_rgba(c, method, all_focus, a_in);
-    // every other render (all-focus, debug modes, weights outside [0, 2) or summing above 2) goes through the RGBA kernels into a
+    if(persist_writes_planar_views(c, method, all_focus, a_in))
+        // all-focus TEN_WM: blend_persist writes the byte planes itself (quad transposes in its epilogue: store_tile_planar)
+        return launch_blend_rgba(c, method, all_focus, a_in);
+    // every other render (all-focus STD, debug modes, weights outside [0, 2) or summing above 2) goes through the RGBA kernels into a
     // scratch copy of the views and is converted to byte planes afterwards
     const size_t need = rgba_out_plane_bytes(c) * c->views_n;
     if(c->rgba_scratch_bytes != need)

@@ -54,8 +54,11 @@ def test_golden_fixtures_planar_layout(case, gpu):
     ctx.render("STD", all_focus=True)
     ctx.sync()
     assert (ctx.download_views() == g["af_std"]).all()
+    ws_before = ctx.memory_info().workspace_bytes
     ctx.render("TEN_WM", all_focus=True)
     ctx.sync()
+    # round 4: blend_persist writes the byte planes itself (quad transposes in its epilogue): no growth of the RGBA scratch copy
+    assert ctx.last_kernel_name() == "blend_persist<TEN_WM,allfocus>" and ctx.memory_info().workspace_bytes == ws_before
     assert np.abs(ctx.download_views().astype(int) - g["af_ten_m16_map0"].astype(int)).max() <= TEN_TOL_LSB
     ctx.close()
 

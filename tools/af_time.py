@@ -1,6 +1,6 @@
 """Config 5 on the structured scene: all-focus render times, estimated and constant map (LFI_AB_LIB selects a differently built library).
 usage: python tools/af_time.py [methods=STD,TEN_WM]"""
-import sys
+import os, sys
 sys.path.insert(0, ".")
 import tools._ablib  # noqa
 import numpy as np
@@ -10,7 +10,7 @@ cols = rows = 15; W, H, V = 3840, 2160, 64
 ctx = L.Context(0); ctx.set_grid(cols, rows, W, H)
 ctx.set_params(L.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.22, 0.17, 7.0, 1.783, V))
 ctx.fill_synthetic_scene(0x1F1F)
-import os
+ctx.set_output_layout(os.environ.get("LFI_LAYOUT", "rgba"))   # LFI_LAYOUT=planar: the all-focus renders into the planar view layout
 if os.environ.get("LFI_TEN_VARIANT"):
     ctx.set_variant("TEN_WM", os.environ["LFI_TEN_VARIANT"])
 if os.environ.get("LFI_STD_VARIANT"):
