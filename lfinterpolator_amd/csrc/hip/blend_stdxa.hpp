@@ -33,7 +33,9 @@ __device__ __forceinline__ void sxa_for_each_unit(F &&f)
 }
 
 // NCH: chunks of 64 images (1 … 4).  One launch renders views [a.v0, min(a.v1, a.v0 + 64)).
-template <bool NT_STORE, int NCH>
+// PLANAR_VIEWS (round 4): the views are the planar layout's byte planes [view][R,G,B][out_rows][views_pitch]; the four lanes of a quad transpose
+// their RGBA dwords (store_tile_planar, blend_core.hpp) and the chain's patches address a byte of a plane.
+template <bool NT_STORE, int NCH, bool PLANAR_VIEWS = false>
 __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const int tiles_x, const int n_tiles)
 {
     static_assert(NCH >= 1 && NCH <= 4, "one to four chunks of 64 images");
@@ -51,6 +53,13 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
     const uint32_t *grid32 = reinterpret_cast<const uint32_t *>(a.grid);
     const size_t plane_px = (size_t)W * (size_t)a.in_rows;
     const size_t oplane_px = (size_t)W * (size_t)a.out_rows;
+    // the byte of (view a.v0 + view, pixel px of the wave's 32 at row ty / column xw, channel c) in the views
+    auto out_byte = [&](const int ty, const int xw, const uint32_t view, const uint32_t px, const uint32_t c) -> uint8_t * {
+        if constexpr(PLANAR_VIEWS)
+            return a.views + (((size_t)(a.v0 + int(view)) * 3 + c) * a.out_rows + ty) * a.views_pitch + (xw + int(px));
+        else
+            return a.views + (((size_t)(a.v0 + int(view)) * oplane_px + (size_t)ty * W + xw + px) * 4 + c);
+    };
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t((lds_ptr_t)lds)));
     typedef const __attribute__((address_space(4))) float *const_float_ptr;
     const const_float_ptr c_offsets = (const_float_ptr)(uintptr_t)a.offsets;
@@ -223,6 +232,9 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
             const bool lane_x_ok = xw + r < W;
             uint8_t *plane0 = a.views + ((size_t)a.v0 * oplane_px + (size_t)ty * W + xw) * 4;
             const uint32_t lane_off = (uint32_t(r) + uint32_t(4 * h) * uint32_t(oplane_px)) * 4u;
+            uint8_t *pbase = PLANAR_VIEWS ? a.views + ((size_t)a.v0 * 3 * a.out_rows + ty) * a.views_pitch + xw : nullptr;
+            uint32_t plane_e = uint32_t(a.out_rows) * uint32_t(a.views_pitch);
+            asm volatile("" : "+s"(plane_e));
             if(xw < W)
             {
 #pragma unroll
@@ -254,8 +266,27 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
                         }
                         const uint32_t rg = __builtin_amdgcn_perm(bits[1], bits[0], 0x0c0c0400u); // [R, G, 0, 0]
                         const uint32_t rgba = __builtin_amdgcn_perm(bits[2], rg, 0x0d040100u);  // [R, G, B, 0xff]
-                        uint32_t *out = reinterpret_cast<uint32_t *>(plane0 + (size_t)(m * 32 + vrow) * oplane_px * 4 + lane_off);
                         prev_stores++; // lane (r = 0, h = 0) is active whenever vrow < nvalid and xw < W: the store is issued
+                        if constexpr(PLANAR_VIEWS)
+                        {
+                            // the quad's 4 × 4 bytes transposed: lanes 0 / 2 / 1 of a quad hold four R / G / B bytes (store_tile_planar)
+                            const uint32_t swapped = uint32_t(__builtin_amdgcn_mov_dpp(int(rgba), 0xB1, 0xf, 0xf, false));
+                            const uint32_t pair = __builtin_amdgcn_perm(swapped, rgba, (r & 1) ? 0x03070206u : 0x05010400u);
+                            const uint32_t other = uint32_t(__builtin_amdgcn_mov_dpp(int(pair), 0x4E, 0xf, 0xf, false));
+                            const uint32_t px4 = __builtin_amdgcn_perm(other, pair, (r & 2) ? 0x03020706u : 0x05040100u);
+                            const int role = (r & 3) == 0 ? 0 : ((r & 3) == 2 ? 1 : ((r & 3) == 1 ? 2 : 3));
+                            if(role < 3 && vrow + 4 * h < nvalid) // (past the right edge: the row's padding — the pitch is a multiple of 128)
+                            {
+                                // wave-uniform base + a 32-bit offset (64 views × 3 planes < 4 GB: checked on the host), the plane size opaque per tile
+                                uint32_t *o4 = reinterpret_cast<uint32_t *>(pbase + (3u * uint32_t(m * 32 + vrow + 4 * h) + uint32_t(role)) * plane_e + uint32_t(r & ~3));
+                                if constexpr(NT_STORE)
+                                    __builtin_nontemporal_store(px4, o4);
+                                else
+                                    *o4 = px4;
+                            }
+                            continue;
+                        }
+                        uint32_t *out = reinterpret_cast<uint32_t *>(plane0 + (size_t)(m * 32 + vrow) * oplane_px * 4 + lane_off);
                         if(lane_x_ok && vrow + 4 * h < nvalid)
                         {
                             if constexpr(NT_STORE)
@@ -326,7 +357,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
                             const float w = static_cast<float>(__builtin_bit_cast(_Float16, wrow[g]));
                             s = __builtin_fmaf(static_cast<float>(p), w, s);
                         }
-                        (plane0 + ((size_t)view * oplane_px + r) * 4)[c] = static_cast<uint8_t>(byte_of15(s));
+                        *out_byte(ty, xw, view, uint32_t(r), uint32_t(c)) = static_cast<uint8_t>(byte_of15(s));
                     }
                 }
                 count += n;
@@ -346,11 +377,10 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
         {
             // the chain's bytes over the rounded ones (same wave as the dword stores: in order).  Not counted in prev_stores (an undercount
             // only makes the next wait stricter).
-            uint8_t *plane0 = a.views + ((size_t)a.v0 * oplane_px + (size_t)ty * W + xw) * 4;
             if(entry0 & 0x8000u)
-                (plane0 + ((size_t)((entry0 >> 5) & 63u) * oplane_px + (entry0 & 31u)) * 4)[(entry0 >> 11) & 3u] = static_cast<uint8_t>(byte_of(s0));
+                *out_byte(ty, xw, (entry0 >> 5) & 63u, entry0 & 31u, (entry0 >> 11) & 3u) = static_cast<uint8_t>(byte_of(s0));
             if(queued > 64 && (entry1 & 0x8000u))
-                (plane0 + ((size_t)((entry1 >> 5) & 63u) * oplane_px + (entry1 & 31u)) * 4)[(entry1 >> 11) & 3u] = static_cast<uint8_t>(byte_of(s1));
+                *out_byte(ty, xw, (entry1 >> 5) & 63u, entry1 & 31u, (entry1 >> 11) & 3u) = static_cast<uint8_t>(byte_of(s1));
         }
         if(!have_next)
             return false;

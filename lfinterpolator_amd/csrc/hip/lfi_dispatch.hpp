@@ -170,18 +170,29 @@ void launch_std_filtered_t(const lfi_ctx *c, const KernelArgs &a_in, bool all_fo
             return;
         }
         note_kernel(c, "blend_stdxa<STD,allfocus>");
+        // the planar layout's byte planes written by the kernel itself (launch_blend: stdxa_writes_planar_views)
+        const bool planar_views_af = a_in.views == c->views && c->out_layout == LFI_LAYOUT_PLANAR_RGB;
         for(int v0 = a_in.v0; v0 < a_in.v1; v0 += 64)
         {
             KernelArgs a = a_in;
             a.v0 = v0;
             a.v1 = std::min(v0 + 64, a_in.v1);
+#define LFI_SXA_LAUNCH(N)                                                                                                                       \
+    do                                                                                                                                          \
+    {                                                                                                                                           \
+        if(planar_views_af)                                                                                                                     \
+            hipLaunchKernelGGL((lfi::blend_stdxa<true, N, true>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles);                           \
+        else                                                                                                                                    \
+            hipLaunchKernelGGL((lfi::blend_stdxa<true, N>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles);                                 \
+    } while(0)
             switch(nch)
             {
-                case 1: hipLaunchKernelGGL((lfi::blend_stdxa<true, 1>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
-                case 2: hipLaunchKernelGGL((lfi::blend_stdxa<true, 2>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
-                case 3: hipLaunchKernelGGL((lfi::blend_stdxa<true, 3>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
-                default: hipLaunchKernelGGL((lfi::blend_stdxa<true, 4>), grid, block, 0, stream_of(c), a, tiles_x, n_tiles); break;
+                case 1: LFI_SXA_LAUNCH(1); break;
+                case 2: LFI_SXA_LAUNCH(2); break;
+                case 3: LFI_SXA_LAUNCH(3); break;
+                default: LFI_SXA_LAUNCH(4); break;
             }
+#undef LFI_SXA_LAUNCH
         }
         return;
     }
@@ -511,6 +522,13 @@ bool persist_writes_planar_views(const lfi_ctx *c, int method, int all_focus, co
            !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH);
 }
 
+// … and blend_stdxa those of this all-focus STD render?  (the default STD variant, weights for which the band method's bounds hold)
+bool stdxa_writes_planar_views(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
+{
+    return c->out_layout == LFI_LAYOUT_PLANAR_RGB && method == LFI_METHOD_STD && all_focus && c->std_variant == 0 && c->weights_scalable && c->weights_sum_ok &&
+           !a.prequant && a.k_pad <= 4 * 64 && (uint64_t)192 * (uint64_t)c->out_rows * (uint64_t)view_pitch(c) < (1ull << 32);
+}
+
 // Does a render with these arguments read the derived planar copy of the inputs?  ONE predicate for launch_blend's two branches,
 // lfi_prepare and lfi_benchmark (round 2: lfi_prepare tested wants_planar only and built nothing for launches that blend_p3 serves
 // beyond wants_planar's view limit — 256 views from 64 images — so the first render carried the build).
@@ -656,10 +674,10 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
     if(stdx_writes_planar_views(c, method, all_focus, a_in) && ensure_planar(c, tune_planar_now(c)))
         // fixed-focus STD: blend_stdx writes the byte planes itself (a.views are the context's planar views)
         return launch_blend_rgba(c, method, all_focus, a_in);
-    if(persist_writes_planar_views(c, method, all_focus, a_in))
-        // all-focus TEN_WM: blend_persist writes the byte planes itself (quad transposes in its epilogue: store_tile_planar)
+    if(persist_writes_planar_views(c, method, all_focus, a_in) || stdxa_writes_planar_views(c, method, all_focus, a_in))
+        // all-focus renders: blend_persist / blend_stdxa write the byte planes themselves (quad transposes in their epilogues: store_tile_planar)
         return launch_blend_rgba(c, method, all_focus, a_in);
-    // every other render (all-focus STD, debug modes, weights outside [0, 2) or summing above 2) goes through the RGBA kernels into a
+    // every other render (debug modes, non-default variants, weights outside [0, 2) or summing above 2) goes through the RGBA kernels into a
     // scratch copy of the views and is converted to byte planes afterwards
     const size_t need = rgba_out_plane_bytes(c) * c->views_n;
     if(c->rgba_scratch_bytes != need)

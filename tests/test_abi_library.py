@@ -111,7 +111,7 @@ def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_pat
     pipelined = [k for k in kernels if any(s in k for s in ("blend_p3", "blend_planar", "blend_persist", "blend_wave", "blend_stdx", "blend_afs", "blend_aft"))]
     assert sum("blend_afsI" in k for k in pipelined) == 2     # all-focus STD, every sample gathered once: three and four chunks
     assert sum("blend_stdxI" in k for k in pipelined) == 8    # fixed focus: one to four chunks of images, RGBA and planar views
-    assert sum("blend_stdxaI" in k for k in pipelined) == 4   # all-focus: one to four chunks
+    assert sum("blend_stdxaI" in k for k in pipelined) == 8   # all-focus: one to four chunks, RGBA and planar views
     assert len(pipelined) >= 10, sorted(kernels)
     # <true, chunks, ablation, view groups per wave, view passes, RGBA epilogue>
     p3_name = re.compile(r"blend_p3ILb1ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])EEEv")

@@ -763,9 +763,10 @@ def test_all_focus_std_band_method(cols, rows, W, H, V, kind, gpu, oracle_c):
             ctx.sync()
             assert ctx.last_kernel_name() == "blend_persist<STD,allfocus>" and (ctx.download_views() == want).all()
             ctx.set_variant("STD", "auto")
-            ctx.set_output_layout("planar")               # RGBA scratch + conversion
+            ctx.set_output_layout("planar")               # round 4: blend_stdxa writes the byte planes itself (quad transposes, byte patches into planes)
             ctx.render("STD", all_focus=True)
             ctx.sync()
+            assert ctx.last_kernel_name() == "blend_stdxa<STD,allfocus>" and ctx.memory_info().workspace_bytes == 0
             assert (ctx.download_views() == want).all(), (kind, "planar layout")
         ctx.close()
     if H >= 4:
