@@ -177,6 +177,16 @@ def test_config5_15x15_4k_bands(gpu, oracle_c):
             ref = oracle_c.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, v0=v, v1=v + 1, rows=(y0, y1), threads=THREADS,
                                      all_focus=True, map_plane=map0, focus=hp.focus, rng=hp.range)
             assert np.abs(af_ten[v][y0:y1].astype(int) - ref[v, y0:y1].astype(int)).max() <= 1, ("all-focus TEN_WM", v, y0)
+
+    # the planar view layout at full size (round 4: every kernel of the default variants writes the byte planes itself — blend_stdx, and
+    # blend_stdxa / blend_persist with quad transposes in their epilogues): whole frames byte-identical to the RGBA layout's, no scratch copy
+    ctx.set_output_layout("planar")
+    for what, all_focus, method, want in (("STD", False, "STD", std), ("all-focus STD", True, "STD", af_std), ("all-focus TEN_WM", True, "TEN_WM", af_ten)):
+        ctx.render(method, all_focus=all_focus)
+        ctx.sync()
+        for v in probe:
+            got = ctx.download_view(v)
+            assert (got == want[v]).all(), (what, "planar layout", v, int((got != want[v]).sum()))
     ctx.close()
 
 
