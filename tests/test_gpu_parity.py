@@ -994,7 +994,14 @@ def test_row_band_sharding_all_focus(world, gpu, oracle_c):
         for method in ("STD", "TEN_WM"):
             ctx.render(method, all_focus=True)
             ctx.sync()
-            got[method] |= ctx.download_views()
+            part = ctx.download_views()
+            got[method] |= part
+            # the band into the planar view layout (round 4: the all-focus kernels write the byte planes themselves): the same bytes
+            ctx.set_output_layout("planar")
+            ctx.render(method, all_focus=True)
+            ctx.sync()
+            assert (ctx.download_views() == part).all(), (method, "planar views of the band", rank)
+            ctx.set_output_layout("rgba")
         ctx.close()
     assert (got_map1 == want_maps[1]).all()
     # against the oracle: both maps of the bands, STD bit-exact from map 1, TEN_WM within one LSB from map 0 (src/kernels.cu:326, :430)

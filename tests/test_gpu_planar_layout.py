@@ -156,8 +156,12 @@ def test_planar_layout_row_bands(world, cols, W, gpu, oracle_c):
     full.render("TEN_WM")
     full.sync()
     want = full.download_views()
+    full.render("STD")
+    full.sync()
+    want_std = full.download_views()
     full.close()
     got = np.zeros_like(want)
+    got_std = np.zeros_like(want)
     for rank in range(world):
         band = gpu.row_band(H, world, rank)
         in_rows = gpu.input_rows(band, hp.focused_offsets, H)
@@ -174,7 +178,12 @@ def test_planar_layout_row_bands(world, cols, W, gpu, oracle_c):
         part = ctx.download_views()
         assert (part[:, :band[0]] == 0).all() and (part[:, band[1]:] == 0).all()
         got |= part
+        ctx.render("STD")           # round 4: blend_stdx writes the band's byte planes itself (one chunk of images or several)
+        ctx.sync()
+        assert ctx.last_kernel_name() == "blend_stdx<STD>"
+        got_std |= ctx.download_views()
         ctx.close()
+    assert (got_std == want_std).all(), "planar row bands of STD differ from the unsharded RGBA render"
     assert np.abs(got.astype(int) - m16.astype(int)).max() <= TEN_TOL_LSB, "planar row bands differ from the oracle's M16"
     assert (got[..., 3] == 255).all()
     assert (got == want).all()
