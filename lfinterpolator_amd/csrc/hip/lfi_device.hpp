@@ -51,9 +51,10 @@ struct KernelArgs
     // planar copy of the inputs (blend_planar.hpp), or nullptr: [image][channel R,G,B][rows held][planar_pitch] bytes,
     // pixel x of a row at byte x + planar_padx, edges replicated into the padding
     const uint8_t *__restrict__ planar;
-    // … plus a per-image phase 0…3 (planar_phase[g]): pixel x of image g sits at byte x + planar_padx + planar_phase[g], chosen when the
-    // copy is built so that the runs of the offsets in use then start on a dword (byte-misaligned LDS-DMA runs cost ≈ 5 %,
-    // tools/align_probe.py); any other offsets are served correctly from the same copy, only their runs start on odd bytes
+    // … plus a per-image phase 0…127 (planar_phase[g]): pixel x of image g sits at byte x + planar_padx + planar_phase[g], chosen when the
+    // copy is built so that the 128-byte runs of the offsets in use then ARE cache lines (the pitch is a multiple of 128; round 3 aligned to
+    // dwords only: the boundary sectors a run shares with its neighbours were fetched twice — 10–19 % of the reads on 15×15 grids); any
+    // other offsets are served correctly from the same copy, only their runs straddle lines
     const int32_t *__restrict__ planar_phase;
     int32_t planar_pitch, planar_padx;
     int32_t views_pitch;                    // planar view layout (blend_p3.hpp): bytes per row of a byte plane [view][R,G,B][out_rows][views_pitch]

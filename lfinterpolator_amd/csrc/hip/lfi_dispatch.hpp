@@ -352,6 +352,12 @@ int next_sweep_direction(const lfi_ctx *c)
 // launches, tools/align_probe.py) — a rebuild.  lfi_prepare / lfi_benchmark ask for it; launch_blend asks once the same offsets have
 // been rendered a few times (the reference's 100-launch loop, a trajectory streamed at one focus), so a focus sweep — new offsets
 // every render — never pays a rebuild per render.
+// LFI_PLANAR_ALIGN: what the runs of the offsets in use are aligned to by the per-image phases — 128 (round 4): a tile's 128-byte run of
+// an image row is then exactly ONE cache line (no boundary sectors fetched with the neighbouring tiles: the launches of several chunks
+// over-fetched 10–19 %, profiles/r04_pmc_traffic_summary.txt); 4 = round 3's dword alignment.  Power of two, ≤ 128.
+#ifndef LFI_PLANAR_ALIGN
+#define LFI_PLANAR_ALIGN 128
+#endif
 bool ensure_planar(lfi_ctx *c, bool tune = false)
 {
     if(!c->grid_tracked)
@@ -364,7 +370,7 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     const bool valid = c->planar && c->planar_version == c->grid_version && c->planar_reach >= reach && (int)c->planar_phase.size() == c->n;
     auto tuned = [&] {
         for(int g = 0; g < c->n; g++)
-            if((c->h_focused[g].x + c->planar_padx + c->planar_phase[g]) & 3)
+            if((c->h_focused[g].x + c->planar_padx + c->planar_phase[g]) & (LFI_PLANAR_ALIGN - 1))
                 return false;
         return true;
     };
@@ -401,7 +407,9 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     const int built_for = c->planar && reach > c->planar_reach ? reach + reach / 4 + 8 : std::max(reach, c->planar_reach);
     const int padx = (built_for + 3) / 4 * 4;
     const int tiles_w = (c->width + 127) / 128 * 128;
-    int pitch = (padx + 3 + tiles_w + built_for + 15) / 16 * 16; // + 3: the largest phase
+    constexpr int pitch_unit = LFI_PLANAR_ALIGN > 16 ? LFI_PLANAR_ALIGN : 16; // rows start on the alignment unit
+    int pitch = (padx + (LFI_PLANAR_ALIGN - 1) + tiles_w + built_for + pitch_unit - 1) / pitch_unit * pitch_unit; // + the largest phase
+    // (an odd number of lines per row — 8×8 @4K comes to a pitch of 4096 bytes — measured ± 2 % either way: profiles/r04_planar_align_ab.txt)
 #ifdef LFI_MEASUREMENT_BUILD // tools/plane_skew.py: do the 192 plane streams collide on HBM channels?  Extra bytes per plane row / per plane.
     static const int extra_pitch = [] { const char *e = std::getenv("LFI_PLANAR_EXTRA_PITCH"); return e ? std::atoi(e) : 0; }();
     pitch += extra_pitch / 16 * 16;
@@ -432,7 +440,7 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
         c->d_planar_phase = nullptr;
         return false;
     }
-    // the phases: (offset + padx + phase) ≡ 0 mod 4 for the offsets in use now.  They travel through one of two page-locked buffers and a
+    // the phases: (offset + padx + phase) ≡ 0 mod LFI_PLANAR_ALIGN for the offsets in use now.  They travel through one of two page-locked buffers and a
     // stream-ordered copy (as lfi_set_params' blob does): kernels of earlier launches that read the old phases are ordered before the
     // copy, the build and every later launch after it, and the host never waits for the stream (round 3 copied from a pageable vector
     // and synchronised the stream inside lfi_render).
@@ -451,7 +459,7 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     c->planar_phase.assign(c->n, 0);
     int32_t *staged = c->phase_staging + (size_t)c->phase_slot * LFI_MAX_IMAGES;
     for(int g = 0; g < c->n; g++)
-        staged[g] = c->planar_phase[g] = (4 - ((c->h_focused[g].x + padx) & 3)) & 3;
+        staged[g] = c->planar_phase[g] = (LFI_PLANAR_ALIGN - ((c->h_focused[g].x + padx) & (LFI_PLANAR_ALIGN - 1))) & (LFI_PLANAR_ALIGN - 1);
     c->planar_version = 0;
     if(hipMemcpyAsync(c->d_planar_phase, staged, sizeof(int32_t) * c->n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
        hipEventRecord(c->ev_phase[c->phase_slot], c->stream) != hipSuccess)
