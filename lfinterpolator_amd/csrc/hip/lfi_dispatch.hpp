@@ -409,7 +409,8 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     const int tiles_w = (c->width + 127) / 128 * 128;
     constexpr int pitch_unit = LFI_PLANAR_ALIGN > 16 ? LFI_PLANAR_ALIGN : 16; // rows start on the alignment unit
     int pitch = (padx + (LFI_PLANAR_ALIGN - 1) + tiles_w + built_for + pitch_unit - 1) / pitch_unit * pitch_unit; // + the largest phase
-    // (an odd number of lines per row — 8×8 @4K comes to a pitch of 4096 bytes — measured ± 2 % either way: profiles/r04_planar_align_ab.txt)
+    // (one more line per row where the pitch comes to a multiple of 2048 bytes — 8×8 @4K: exactly 4096 —, or an odd number of lines per row for
+    // every shape: measured, ± 2 % either way by box: profiles/r04_planar_align_ab.txt)
 #ifdef LFI_MEASUREMENT_BUILD // tools/plane_skew.py: do the 192 plane streams collide on HBM channels?  Extra bytes per plane row / per plane.
     static const int extra_pitch = [] { const char *e = std::getenv("LFI_PLANAR_EXTRA_PITCH"); return e ? std::atoi(e) : 0; }();
     pitch += extra_pitch / 16 * 16;
