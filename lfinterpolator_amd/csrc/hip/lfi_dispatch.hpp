@@ -487,17 +487,14 @@ bool tune_planar_now(lfi_ctx *c)
     return c->launches_with_offsets++ >= LFI_RETUNE_AFTER;
 }
 
-// Would this launch read the planar copy of the inputs?  It pays where reads are a large share of the traffic: not for launches
-// that write many more views than they read images (config 4 on one GPU, 256 views from 64 images: +6 % — the byte-wise operand
-// assembly repeats per view pass).
+// Would this launch read the planar copy of the inputs?
 bool wants_planar(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
 {
     if(all_focus || a.prequant || !c->weights_scalable)
         return false;
-    // (TEN_WM only: STD's alternative there is the exact-fp32 kernel — 256 views from 64 images at 4K: 7.2 ms against 3.4 with the band method
-    // on the planar copy, profiles/r04_rgba_p3_ab.txt)
-    if(method == LFI_METHOD_TEN_WM && a.v1 - a.v0 > std::max(c->n, 64) && !c->inputs_released)
-        return false;
+    // (Rounds 2–3 kept launches that write many more views than they read images — 256 views from 64 images — off the copy: +6 % then.  With the
+    // line-aligned copy it is the faster source there too: TEN_WM with RGBA views 2.04 against 2.17–2.28 ms, STD 3.6 against 7.2 ms for the
+    // exact-fp32 kernel, profiles/r04_rgba_p3_ab.txt.)
     if(method == LFI_METHOD_TEN_WM)
         return kTenVariants[c->ten_variant].planar && !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH);
     // STD: blend_planar<STDF> (one chunk of images) / blend_stdx (up to four) — weights for which their error bounds hold
