@@ -2,7 +2,8 @@
 //
 //   blend_afs  STD     Kernels::Standard::process<true> (reference src/kernels.cu:312-342): the exact fp32 fmaf chain over per-pixel
 //                      warped samples, by the band method of blend_stdx.hpp / blend_stdxa.hpp — with every sample gathered ONCE.
-//   blend_aft  TEN_WM  Kernels::Tensors::process<true> (src/kernels.cu:398-461, warp at :78-82) on the same pipeline.
+//   (blend_aft, a TEN_WM kernel on the same pipeline, was built, measured slower than blend_persist — 3.02 against 2.65 ms at config 5 — and
+//    removed in round 4: profiles/r04_notes.md §9.)
 //
 // Why a second all-focus STD kernel.  blend_stdxa (round 3) keeps blend_persist's geometry — tiles of 128 pixels, two 32 KB pixel buffers per
 // workgroup — so a tile's stack of 225 images (115 KB) does not stay in LDS, and the chain's bytes of chunks 2 and 3 are gathered a SECOND

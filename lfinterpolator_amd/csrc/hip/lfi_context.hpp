@@ -56,6 +56,7 @@ struct lfi_ctx
     // the planar kernels only); a later lfi_upload_image goes through a one-image staging plane straight into the copy
     bool inputs_released = false;
     uint8_t *stage_plane = nullptr;
+    size_t stage_plane_bytes = 0;
     // set by lfi_prepare for a render that reads the planar copy: from then on images that arrive (lfi_upload_image, lfi_fill_synthetic_images)
     // refresh their planes of the copy AT ONCE instead of at the next render — the first render after a load is then only a launch
     bool eager_planar = false;
@@ -433,6 +434,17 @@ void free_views(lfi_ctx *c)
     c->quality_ref_bytes = 0;
 }
 
+// the one-image staging plane of uploads after lfi_release_inputs is sized by the row window in force when it was allocated, and the eager
+// refresh lfi_prepare switched on belongs to the planes it was switched on for: both go whenever the input planes are replaced
+void drop_stage_plane(lfi_ctx *c)
+{
+    if(c->stage_plane)
+        (void)hipFree(c->stage_plane);
+    c->stage_plane = nullptr;
+    c->stage_plane_bytes = 0;
+    c->eager_planar = false;
+}
+
 void free_grid(lfi_ctx *c)
 {
     if(c->own_grid && c->grid)
@@ -441,10 +453,7 @@ void free_grid(lfi_ctx *c)
     c->own_grid = false;
     c->grid_bytes = 0;
     c->inputs_released = false;
-    c->eager_planar = false;
-    if(c->stage_plane)
-        (void)hipFree(c->stage_plane);
-    c->stage_plane = nullptr;
+    drop_stage_plane(c);
     if(c->maps)
         (void)hipFree(c->maps);
     c->maps = nullptr;

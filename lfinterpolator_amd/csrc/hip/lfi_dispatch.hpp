@@ -198,6 +198,8 @@ void launch_std_filtered_t(const lfi_ctx *c, const KernelArgs &a_in, bool all_fo
     }
     if(!a_in.planar || all_focus || a_in.k_pad > 4 * lfi::P3_KC)
     {
+        // (launch_blend hands this launcher the planar byte views only together with a valid planar copy or for the all-focus branch above:
+        // the RGBA-store kernels below never see them)
         launch_wave<true, 2, true>(c, a_in, all_focus);
         return;
     }
@@ -524,8 +526,10 @@ bool stdx_writes_planar_views(const lfi_ctx *c, int method, int all_focus, const
 // blend_persist for all-focus renders —, weights in [0, 2) for the packed epilogue, no debug modes)
 bool persist_writes_planar_views(const lfi_ctx *c, int method, int all_focus, const KernelArgs &a)
 {
+    // store_tile_planar (blend_core.hpp) addresses (3·view + channel)·plane bytes for up to 32 views of a pass with one 32-bit offset
+    const bool planes_fit = (uint64_t)96 * (uint64_t)c->out_rows * (uint64_t)view_pitch(c) < (1ull << 32);
     return c->out_layout == LFI_LAYOUT_PLANAR_RGB && method == LFI_METHOD_TEN_WM && all_focus && c->ten_variant <= 1 && c->weights_scalable && !a.prequant &&
-           !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH);
+           !(c->flags & LFI_FLAG_TEN_ROUND_PER_BATCH) && planes_fit;
 }
 
 // … and blend_stdxa those of this all-focus STD render?  (the default STD variant, weights for which the band method's bounds hold)
@@ -652,7 +656,10 @@ void launch_p3(const lfi_ctx *c, const KernelArgs &a_in, bool rgba_out)
     }
 }
 
-int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in);
+// planar_decided: launch_blend has already made the derived copy valid for this launch (ensure_planar succeeded there) — the copy is
+// taken as it is, no second ensure_planar (the second call counted the launch twice and could be the one that rebuilds and fails,
+// after launch_blend had committed to kernels that write byte planes)
+int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in, bool planar_decided = false);
 
 int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
 {
@@ -679,7 +686,7 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
     }
     if(stdx_writes_planar_views(c, method, all_focus, a_in) && ensure_planar(c, tune_planar_now(c)))
         // fixed-focus STD: blend_stdx writes the byte planes itself (a.views are the context's planar views)
-        return launch_blend_rgba(c, method, all_focus, a_in);
+        return launch_blend_rgba(c, method, all_focus, a_in, true);
     if(persist_writes_planar_views(c, method, all_focus, a_in) || stdxa_writes_planar_views(c, method, all_focus, a_in))
         // all-focus renders: blend_persist / blend_stdxa write the byte planes themselves (quad transposes in their epilogues: store_tile_planar)
         return launch_blend_rgba(c, method, all_focus, a_in);
@@ -707,10 +714,10 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
     return LFI_OK;
 }
 
-int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
+int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in, bool planar_decided)
 {
     KernelArgs a = a_in;
-    if(wants_planar(c, method, all_focus, a) && ensure_planar(c, tune_planar_now(c)))
+    if(planar_decided || (wants_planar(c, method, all_focus, a) && ensure_planar(c, tune_planar_now(c))))
     {
         a.planar = c->planar;
         a.planar_pitch = c->planar_pitch;

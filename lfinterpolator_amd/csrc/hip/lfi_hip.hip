@@ -209,6 +209,7 @@ int lfi_set_row_window(lfi_ctx *ctx, int out_y0, int out_y1, int in_y0, int in_y
     ctx->grid = nullptr;
     ctx->own_grid = false;
     ctx->inputs_released = false;
+    drop_stage_plane(ctx); // sized for the window in force when it was allocated (a larger window overflowed it)
     ctx->in_y0 = in_y0;
     ctx->in_rows = in_y1 - in_y0;
     ctx->out_y0 = out_y0;
@@ -237,8 +238,13 @@ int lfi_upload_image(lfi_ctx *ctx, int g, const uint8_t *rgba, size_t pitch_byte
     if(ctx->inputs_released)
     {
         // the RGBA planes are gone: the image goes through a one-image staging plane straight into its planes of the planar copy
+        if(ctx->stage_plane && ctx->stage_plane_bytes < in_plane_bytes(ctx))
+            drop_stage_plane(ctx);
         if(!ctx->stage_plane)
+        {
             LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->stage_plane), in_plane_bytes(ctx)));
+            ctx->stage_plane_bytes = in_plane_bytes(ctx);
+        }
         LFI_HIP(ctx, hipMemcpy2DAsync(ctx->stage_plane, (size_t)ctx->width * 4, rgba + (size_t)ctx->in_y0 * pitch_bytes, pitch_bytes, (size_t)ctx->width * 4,
                                       ctx->in_rows, hipMemcpyHostToDevice, ctx->stream));
         // planar_build reads image g at grid + g·plane: hand it a base that puts the staging plane there
@@ -324,6 +330,7 @@ int lfi_attach_grid(lfi_ctx *ctx, void *device_ptr, size_t bytes)
     ctx->grid = static_cast<uint8_t *>(device_ptr);
     ctx->own_grid = false;
     ctx->inputs_released = false;
+    drop_stage_plane(ctx);
     ctx->grid_bytes = bytes;
     touch_all(ctx);
     ctx->grid_tracked = false; // the caller writes this buffer itself: see lfi_grid_modified
@@ -431,6 +438,8 @@ int lfi_grid_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes)
 {
     if(!ctx || !out_ptr)
         return LFI_EINVAL;
+    if(ctx->inputs_released) // before anything is touched: the query must not cost the context its only copy of the inputs
+        return fail(ctx, LFI_EINVAL, "the RGBA inputs were released (lfi_release_inputs): lfi_set_grid and upload the images again");
     if(ctx->uploads_pending && bind(ctx) == LFI_OK)
         (void)lfi_upload_wait(ctx); // the caller is about to read or write the planes itself
     *out_ptr = ctx->grid;
@@ -1344,12 +1353,12 @@ int lfi_download_coords(lfi_ctx *ctx, int g, int all_focus, int map_index, lfi_i
         return fail(ctx, LFI_EINVAL, "coordinate dumps are not supported with a row window");
     if(int rc = bind(ctx))
         return rc;
+    if(int rc = join_filter(ctx))
+        return rc;
     const size_t bytes = sizeof(lfi_int2) * (size_t)ctx->width * ctx->height;
     lfi_int2 *d = nullptr;
     LFI_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d), bytes));
     KernelArgs a = make_args(ctx, 0, ctx->views_n, LFI_METHOD_STD);
-    if(int rc = join_filter(ctx))
-        return rc;
     a.map_index = map_index;
     hipLaunchKernelGGL(lfi::dump_coords, pixel_grid(ctx), dim3(256), 0, ctx->stream, a, g, all_focus, d);
     hipError_t e = hipGetLastError();

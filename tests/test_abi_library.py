@@ -108,7 +108,7 @@ def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_pat
             kernels[name] = {}
         elif name and ":" in line and line.split(":")[0] in (".private_segment_fixed_size", ".vgpr_spill_count", ".sgpr_spill_count", ".vgpr_count"):
             kernels[name][line.split(":")[0]] = int(line.split(":")[1])
-    pipelined = [k for k in kernels if any(s in k for s in ("blend_p3", "blend_planar", "blend_persist", "blend_wave", "blend_stdx", "blend_afs", "blend_aft"))]
+    pipelined = [k for k in kernels if any(s in k for s in ("blend_p3", "blend_planar", "blend_persist", "blend_wave", "blend_stdx", "blend_afs"))]
     assert sum("blend_afsI" in k for k in pipelined) == 2     # all-focus STD, every sample gathered once: three and four chunks
     assert sum("blend_stdxI" in k for k in pipelined) == 8    # fixed focus: one to four chunks of images, RGBA and planar views
     assert sum("blend_stdxaI" in k for k in pipelined) == 8   # all-focus: one to four chunks, RGBA and planar views

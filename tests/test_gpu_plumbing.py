@@ -538,9 +538,11 @@ def test_release_inputs(cols, rows, V, gpu, oracle_c):
     ctx.set_params(hp)
     check(cur, hp, "released, back to the first offsets")
     # what needs the RGBA planes is refused
-    for call in (lambda: ctx.render("TEN_WM", all_focus=True), lambda: ctx.focus_map(), lambda: ctx.fill_synthetic(1), lambda: ctx.download_coords(0)):
+    for call in (lambda: ctx.render("TEN_WM", all_focus=True), lambda: ctx.focus_map(), lambda: ctx.fill_synthetic(1), lambda: ctx.download_coords(0),
+                 lambda: ctx.grid_device_ptr(), lambda: ctx.grid_modified()):
         with pytest.raises(gpu.LfiError, match="released"):
             call()
+    check(cur, hp, "released, after the refused calls (ADVICE r4: lfi_grid_device_ptr used to cost the context its only copy)")
     ctx.set_variant("TEN_WM", "persist_m2_nt")   # a kernel that reads the RGBA planes
     with pytest.raises(gpu.LfiError, match="released"):
         ctx.render("TEN_WM")
@@ -554,6 +556,24 @@ def test_release_inputs(cols, rows, V, gpu, oracle_c):
     ctx.set_params(hp_large)
     ctx.render("STD", all_focus=False); ctx.sync()
     assert (ctx.download_views() == oracle_c.blend_std(cur, hp_large.focused_offsets, hp_large.offsets, hp_large.weights, threads=8)).all()
+    ctx.close()
+    # release, upload, a LARGER row window, release, upload (the one-image staging plane kept the first window's size and the second
+    # upload overflowed it)
+    ctx = gpu.Context(0)
+    ctx.set_grid(cols, rows, W, H)
+    for band in ((10, 14), (0, H), (11, 13), (0, H)):
+        in_rows = gpu.input_rows(band, hp_small.focused_offsets, H)
+        ctx.set_row_window(band[0], band[1], in_rows[0], in_rows[1])
+        ctx.upload_grid(lf)
+        ctx.set_params(hp_small)
+        ctx.release_inputs()
+        cur = lf.copy()
+        for g in (1, n - 2):
+            cur[g] = other[g]
+            ctx.upload_image(g, other[g])
+        ctx.render("STD"); ctx.sync()
+        want = oracle_c.blend_std(cur, hp_small.focused_offsets, hp_small.offsets, hp_small.weights, threads=8)
+        assert (ctx.download_views()[:, band[0]:band[1]] == want[:, band[0]:band[1]]).all(), band
     ctx.close()
     # the footprint at a BASELINE-like width (padding is relative to the offsets, not to the image count)
     ctx = gpu.Context(0)
