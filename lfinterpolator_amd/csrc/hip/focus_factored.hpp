@@ -109,19 +109,33 @@ __global__ void __launch_bounds__(64) focus_pad(const KernelArgs a, const FocusW
         return;
     const int yy = blockIdx.y, k = k0 + blockIdx.z;
     const int W = a.width, H = a.height;
-    const uint32_t *row = reinterpret_cast<const uint32_t *>(a.grid) + (size_t)a.focus_ids[k] * ((size_t)W * H) +
-                          (size_t)clampi(yy - w.Py, 0, H - 1) * W;
+    const uint32_t *plane = reinterpret_cast<const uint32_t *>(a.grid) + (size_t)a.focus_ids[k] * ((size_t)W * H);
+    const uint32_t *row = plane + (size_t)clampi(yy - w.Py, 0, H - 1) * W;
+    const uint32_t *below = plane + (size_t)clampi(yy + 1 - w.Py, 0, H - 1) * W; // the padded row yy + 1
     const int x = xx - w.Px;
-    u32x4 v;
+    u32x4 v, b;
     if(x >= 0 && x + 3 <= W - 1)
+    {
         v = *reinterpret_cast<const u32x4_a4 *>(row + x);
+        b = *reinterpret_cast<const u32x4_a4 *>(below + x);
+    }
     else
     {
         v.x = row[clampi(x, 0, W - 1)];
         v.y = row[clampi(x + 1, 0, W - 1)];
         v.z = row[clampi(x + 2, 0, W - 1)];
         v.w = row[clampi(x + 3, 0, W - 1)];
+        b.x = below[clampi(x, 0, W - 1)];
+        b.y = below[clampi(x + 1, 0, W - 1)];
+        b.z = below[clampi(x + 2, 0, W - 1)];
+        b.w = below[clampi(x + 3, 0, W - 1)];
     }
+    // The alpha byte of a padded pixel carries the BLUE of the pixel one padded row below (no pass reads alpha: the reference's ElementRange
+    // looks at R, G, B only, src/kernels.cu:173-194): focus_range_t's typed load then returns [R, G | B, B'] — its LDS slot — as it is.
+    v.x = __builtin_amdgcn_perm(b.x, v.x, 0x06020100u);
+    v.y = __builtin_amdgcn_perm(b.y, v.y, 0x06020100u);
+    v.z = __builtin_amdgcn_perm(b.z, v.z, 0x06020100u);
+    v.w = __builtin_amdgcn_perm(b.w, v.w, 0x06020100u);
     *reinterpret_cast<u32x4 *>(w.pad + ((size_t)k * w.Hp + yy) * w.Wp + xx) = v; // Wp is a multiple of 4
 }
 
@@ -489,6 +503,316 @@ __global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const Foc
         uint16_t *dst = w.E + ((size_t)(i0 + c) * w.He_p + ey) * w.We_p + tx * 256 + 4 * lane;
         *reinterpret_cast<u32x2 *>(dst) = acc[c].encode();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// focus_range_t (round 5): E_i(q) with the views' samples UNPACKED ONCE into LDS and reduced from there.
+//
+// focus_range spends half of its vector instructions widening bytes to u16 lanes (a v_perm_b32 per channel pair, per use) and runs at the
+// L1's tag rate; round 4's LDS-staged variant removed the L1 and kept the v_perm's (VALU-paced, the same time).  What the unit probes of
+// round 5 say (tools/probe_range_units.hip, profiles/r05_range_unit_probes.txt): v_pk_minimum3 / maximum3_f16 and v_perm_b32 issue every 5
+// cycles; LDS reads need NATURAL alignment (a ds_read_b64 at a 4-byte boundary runs 20 times slower), so samples addressed per pixel want
+// one 8-byte slot per pixel; the texture path unpacks for free — buffer_load_format_d16_xyzw through a descriptor of format 8_8_8_8 UINT
+// returns an RGBA8 pixel as four u16 in two registers, from any byte address.
+//
+// So: focus_pad stores the BLUE of the pixel one row below in the (unused) alpha byte; a typed load of a padded pixel then IS the slot
+// [R, G | B, B'] and goes to LDS with one ds_write_b64.  A lane owns one column and TWO row pairs of the tile; for the pair (y, y + 1) it
+// reads slot(y) whole and the [R, G] half of slot(y + 1): the three registers (R0,G0), (R1,G1), (B0,B1) — six bytes in u16 lanes, no
+// instruction spent on widening — and reduces two views per v_pk_minimum3 / maximum3_f16: 1.5 vector instructions per (pixel, candidate,
+// view) where focus_range issues 3.  A workgroup = 64 columns × 16 rows of CPW consecutive candidates; per step it stages the patches
+// of TWO views (each the tile plus the span of the group's shifts: at most 96 × 34 pixels) and every staged pixel serves CPW candidates.
+// Host-checked preconditions (launch_focus_factored; else focus_range): within a group a view's shifts span at most 32 pixels and 18 rows.
+constexpr int FRT_TW = 64;                          // tile: extended columns (one per lane); rows: four per wave
+constexpr int FRT_NW = 8, FRT_TH = 4 * FRT_NW;      // waves per workgroup, tile rows
+constexpr int FRT_MAX_DX = 32, FRT_MAX_DY = 18;     // the largest span of a view's shifts within a candidate group
+constexpr int FRT_PW = FRT_TW + FRT_MAX_DX;         // a view's patch in LDS: pixels per row (the row pitch) …
+constexpr int FRT_PR = FRT_TH + FRT_MAX_DY;         // … × rows, at most
+constexpr int FRT_PR_LDS = FRT_PR + 2;              // rows of slots per view in LDS: the patches are fetched in blocks of four rows
+constexpr int FRT_VIEW_B = FRT_PW * FRT_PR_LDS * 8; // 39,936 bytes of 8-byte slots; two views per step, two steps in LDS: 159,744 bytes
+
+// per (candidate group, view): where the view's patch starts in the padded planes, its size, and where each candidate of the group reads
+struct FocusPatch
+{
+    uint32_t src;      // byte offset in the padded planes of the patch's first pixel for the tile at extended (0, 0)
+    uint32_t pw_pr;    // patch width (pixels) | rows << 16
+    uint32_t d[4];     // per candidate c: byte offset of its samples inside the patch, (dy·FRT_PW + dx)·8, u16 pairs (c even: low half)
+    uint32_t unused[2];
+};
+
+typedef _Float16 frt_h4 __attribute__((ext_vector_type(4)));
+typedef int frt_i4 __attribute__((ext_vector_type(4)));
+// buffer_load_format_d16_xyzw (the compiler tracks its vmcnt like any load's)
+__device__ frt_h4 frt_load_format_d16_xyzw(frt_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f16");
+
+// one thread per (group, view slot); after focus_plan_shifts
+template <int CPW>
+__global__ void __launch_bounds__(32) focus_plan_patches(const KernelArgs a, const FocusWork w, FocusPatch *plans)
+{
+    const int group = blockIdx.x, k = threadIdx.x;
+    if(k >= a.n_focus_ids)
+        return;
+    int sx[CPW], sy[CPW], ox = INT32_MAX, oy = INT32_MAX, mx = INT32_MIN, my = INT32_MIN;
+#pragma unroll
+    for(int c = 0; c < CPW; c++)
+    {
+        sx[c] = w.shifts[4 * ((group * CPW + c) * FOCUS_MAX_IDS + k)];
+        sy[c] = w.shifts[4 * ((group * CPW + c) * FOCUS_MAX_IDS + k) + 1];
+        ox = min(ox, sx[c]), oy = min(oy, sy[c]), mx = max(mx, sx[c]), my = max(my, sy[c]);
+    }
+    FocusPatch p{};
+    p.src = uint32_t((((int64_t)k * w.Hp + oy + w.Py) * w.Wp + ox + w.Px) * 4);
+    p.pw_pr = uint32_t(FRT_TW + mx - ox) | (uint32_t(FRT_TH + my - oy) << 16);
+#pragma unroll
+    for(int c = 0; c < CPW; c++)
+        p.d[c >> 1] |= uint32_t(((sy[c] - oy) * FRT_PW + (sx[c] - ox)) * 8) << (16 * (c & 1));
+    plans[group * FOCUS_MAX_IDS + k] = p;
+}
+
+// One workgroup per CU (the patches of two steps fill the LDS): EIGHT REDUCING waves and FOUR LOADING waves.  The texture path takes 16
+// cycles per typed wave-load; issued by the reducing waves themselves — in a burst in front of the barrier, or between the candidates — the
+// loads held every wave while nothing was reduced (the three phases added up: profiles/r05_notes.md).  So the roles are split: the loading
+// waves fetch step s + 1's patches and store its slots into the other half of the LDS while the reducing waves work on step s; ONE barrier
+// per step.  Loading wave L: view L & 1 of the step's pair, rows ≡ L >> 1 (mod 2) of its "main" part (column lane, 64 columns: a patch is at
+// least that wide) and row pairs ≡ L >> 1 (mod 2) of its "extra" part (columns 64 + (lane & 31), row 2·pair + (lane >> 5): all 32 columns
+// whatever the patch's width — columns beyond it land in slots nobody reads).
+constexpr int FRT_LW = 4; // loading waves
+template <int CPW>
+__global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const KernelArgs a, const FocusWork w, const FocusPatch *plans, const uint32_t pad_bytes,
+                                                                           const uint32_t nblocks, const int striped)
+{
+    constexpr int GROUPS = FOCUS_STEPS / CPW;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * FRT_VIEW_B];
+    const uint32_t tiles_x = uint32_t(w.We_p) / FRT_TW, tiles_y = (uint32_t(w.He_p) + FRT_TH - 1) / FRT_TH;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_ids = a.n_focus_ids;
+    // PERSISTENT: one workgroup per CU walks the work items (tile × candidate group) b, b + gridDim.x, … (gridDim.x a multiple of 8: a
+    // workgroup stays on its XCD's items) — a workgroup that owns the whole LDS cannot overlap its successor's start-up with its own tail.
+    // The LDS halves alternate per STEP across items; the barrier protocol needs nothing at an item's end (see below).
+    auto work_item = [&](const uint32_t b, uint32_t &tx, uint32_t &ty, uint32_t &group) {
+        if(striped)
+            return stripe_map(b, tiles_x, tiles_y, GROUPS, tx, ty, group);
+        const uint32_t work = xcd_contiguous(b, nblocks);
+        group = work % GROUPS;
+        tx = (work / GROUPS) % tiles_x;
+        ty = (work / GROUPS) / tiles_x;
+        return true;
+    };
+    uint32_t half = 0; // which half of the LDS the current step's slots are in
+    if(wave >= FRT_NW)
+    {
+        // ---- a loading wave: view lw & 1 of every step's pair; the row blocks ≡ lw >> 1 (mod 2) of its patch.  Loads of FOUR pixels per
+        // lane (buffer_load_dwordx4: the texture path takes 16 cycles per wave-load whatever its width — typed one-pixel loads, which
+        // unpack for free, made it the bottleneck: profiles/r05_notes.md), widened here with two v_perm_b32 per pixel — these waves have
+        // nothing else to compute — and stored as two ds_write_b128 per lane (8-byte stores from one wave per SIMD run at a third of
+        // their rate).  "main": 64 columns × blocks of 4 rows (lane & 15 = quad of pixels, lane >> 4 = row); "extra": the 32 columns behind
+        // them × blocks of 8 rows (lane & 7 = quad, lane >> 3 = row; all 32 columns whatever the patch's width — columns beyond it land
+        // in slots nobody reads, as do rows beyond its height: FRT_PR_LDS rows of slots exist).
+        const int lw = wave - FRT_NW, v = lw & 1, par = lw >> 1;
+        const uint32_t row_b = uint32_t(w.Wp) * 4u;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(w.pad, 0, int(pad_bytes), 0x00020000);
+        const int v_main = (lane >> 4) * int(row_b) + (lane & 15) * 16, v_extra = (lane >> 3) * int(row_b) + 4 * FRT_TW + (lane & 7) * 16;
+        constexpr int MAIN_N = ((FRT_PR + 3) / 4 + 1) / 2, EXTRA_N = ((FRT_PR + 7) / 8 + 1) / 2; // row blocks of one parity
+        constexpr int MAIN_SURE = FRT_TH / 8, EXTRA_SURE = FRT_TH / 16;                           // … that every patch has
+        uint8_t *const st_main = lds + v * FRT_VIEW_B + ((4 * par + (lane >> 4)) * FRT_PW + 4 * (lane & 15)) * 8;
+        uint8_t *const st_extra = lds + v * FRT_VIEW_B + ((8 * par + (lane >> 3)) * FRT_PW + FRT_TW + 4 * (lane & 7)) * 8;
+        const bool extra_tail_ok = 8 * (2 * (EXTRA_N - 1) + par) + (lane >> 3) < FRT_PR_LDS; // the last extra block may reach below the slots
+        uint32_t tile_off = 0;
+        focus_const_u32_ptr plan_words = nullptr;
+        // Two register sets: the loads of step s + 1 are issued BEFORE the slots of step s are stored, so the texture path never idles while
+        // a wave waits for its last load and stores.
+        u32x4 mA[MAIN_N], eA[EXTRA_N], mB[MAIN_N], eB[EXTRA_N];
+        uint32_t prA = 0, prB = 0;
+        auto fetch = [&](const int k, u32x4 (&m)[MAIN_N], u32x4 (&e)[EXTRA_N], uint32_t &pr) {
+            const int kv = min(k + v, n_ids - 1); // an odd tail reduces the last view twice: no minimum or maximum changes
+            const focus_const_u32_ptr pl = plan_words + kv * 8;
+            const uint32_t src = pl[0] + tile_off;
+            pr = pl[1] >> 16;
+#if defined(FRT_ABL) && (FRT_ABL & 1) // measurement builds: no loads (the slots get whatever the registers hold)
+#pragma unroll
+            for(int i = 0; i < MAIN_N; i++)
+                m[i] = u32x4{src + i, pr, src, pr};
+#pragma unroll
+            for(int i = 0; i < EXTRA_N; i++)
+                e[i] = u32x4{src, pr + i, pr, src};
+            return;
+#endif
+#pragma unroll
+            for(int i = 0; i < MAIN_N; i++)
+                if(i < MAIN_SURE || uint32_t(4 * (2 * i + par)) < pr) // wave-uniform: the block's first row
+                    m[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_main, int(src + uint32_t(4 * (2 * i + par)) * row_b), 0);
+#pragma unroll
+            for(int i = 0; i < EXTRA_N; i++)
+                if(i < EXTRA_SURE || uint32_t(8 * (2 * i + par)) < pr)
+                    e[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_extra, int(src + uint32_t(8 * (2 * i + par)) * row_b), 0);
+        };
+        auto put = [&](uint8_t *const dst, const u32x4 px) { // four padded pixels [R,G,B,B'] → four slots [R,G | B,B'] of u16
+            u32x4 s0, s1;
+            s0.x = __builtin_amdgcn_perm(0u, px.x, 0x0c010c00u), s0.y = __builtin_amdgcn_perm(0u, px.x, 0x0c030c02u);
+            s0.z = __builtin_amdgcn_perm(0u, px.y, 0x0c010c00u), s0.w = __builtin_amdgcn_perm(0u, px.y, 0x0c030c02u);
+            s1.x = __builtin_amdgcn_perm(0u, px.z, 0x0c010c00u), s1.y = __builtin_amdgcn_perm(0u, px.z, 0x0c030c02u);
+            s1.z = __builtin_amdgcn_perm(0u, px.w, 0x0c010c00u), s1.w = __builtin_amdgcn_perm(0u, px.w, 0x0c030c02u);
+            *reinterpret_cast<u32x4 *>(dst) = s0;
+            *reinterpret_cast<u32x4 *>(dst + 16) = s1;
+        };
+        auto store = [&](const u32x4 (&m)[MAIN_N], const u32x4 (&e)[EXTRA_N], const uint32_t pr) {
+            // (every wave has passed the previous barrier: the reducing waves are done with this half, which held the step before the one they reduce now)
+#pragma unroll
+            for(int i = 0; i < MAIN_N; i++)
+                if(i < MAIN_SURE || uint32_t(4 * (2 * i + par)) < pr)
+                    put(st_main + half + 8 * i * FRT_PW * 8, m[i]);
+#pragma unroll
+            for(int i = 0; i < EXTRA_N; i++)
+                if(i < EXTRA_SURE || uint32_t(8 * (2 * i + par)) < pr)
+                {
+                    if(i + 1 < EXTRA_N || extra_tail_ok)
+                        put(st_extra + half + 16 * i * FRT_PW * 8, e[i]);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's slots are in LDS
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            half ^= 2u * FRT_VIEW_B;
+        };
+        for(uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x)
+        {
+            uint32_t tx, ty, group;
+            if(!work_item(b, tx, ty, group))
+                continue;
+            // byte offset of the tile's first extended pixel relative to extended (0, 0) (negative near the top / left: modular, added to FocusPatch::src)
+            tile_off = uint32_t((int(ty) * FRT_TH - a.radius_y) * w.Wp + (int(tx) * FRT_TW - a.radius_x)) * 4u;
+            plan_words = (focus_const_u32_ptr)(uintptr_t)(plans + group * FOCUS_MAX_IDS);
+            fetch(0, mA, eA, prA);
+            for(int k = 0; k < n_ids; k += 4)
+            {
+                if(k + 2 < n_ids)
+                    fetch(k + 2, mB, eB, prB);
+                store(mA, eA, prA);
+                if(k + 2 < n_ids)
+                {
+                    if(k + 4 < n_ids)
+                        fetch(k + 4, mA, eA, prA);
+                    store(mB, eB, prB);
+                }
+            }
+        }
+        return;
+    }
+    // ---- a reducing wave: rows 4·wave … 4·wave + 3 of the tile, column lane
+    // LDS address of this lane's column in the first of its four rows
+    const uint32_t rd_addr = uint32_t(uintptr_t((__attribute__((address_space(3))) void *)lds)) + uint32_t(4 * wave * FRT_PW + lane) * 8u;
+    for(uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x)
+    {
+    uint32_t tx, ty, group;
+    if(!work_item(b, tx, ty, group))
+        continue;
+    const focus_const_u32_ptr plan_words = (focus_const_u32_ptr)(uintptr_t)(plans + group * FOCUS_MAX_IDS);
+    // accumulators per candidate: [R,G] of the four rows, [B,B'] of the two row pairs — running minima and maxima
+    u16x2 lo[CPW][6], hi[CPW][6];
+#pragma unroll
+    for(int c = 0; c < CPW; c++)
+#pragma unroll
+        for(int r = 0; r < 6; r++)
+        {
+            lo[c][r] = as_u16x2(0x00ff00ffu);
+            hi[c][r] = as_u16x2(0u);
+        }
+    for(int k = 0; k < n_ids; k += 2)
+    {
+        uint32_t dc[2][4];
+#pragma unroll
+        for(int v = 0; v < 2; v++)
+        {
+            const focus_const_u32_ptr pl = plan_words + min(k + v, n_ids - 1) * 8;
+#pragma unroll
+            for(int q = 0; q < 4; q++)
+                dc[v][q] = pl[2 + q];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the plan words; the previous step's reads were consumed)
+        __builtin_amdgcn_s_barrier();                       // step k's slots are in LDS
+        asm volatile("" ::: "memory");
+        // The reduction.  LDS reads by inline assembly: every slot is read whole (ds_read_b64) although of the second row of a pair only
+        // [R,G] is used — the compiler narrows such a read to ds_read_b32, and 4-byte reads at an 8-byte lane stride run into two-way bank
+        // conflicts (25 % of all LDS cycles, profiles/r05_pmc_range_t_first.txt).  The reads of candidate c + 1 are issued before candidate
+        // c is reduced; LDS returns in order, so lgkmcnt(8) = "the older eight reads have landed" (a scalar load still in flight — the next
+        // step's plan words — only makes the wait longer: it shares the counter).
+        auto slot_addr = [&](const int c, const int v) {
+            return rd_addr + (((dc[v][c >> 1] >> (16 * (c & 1))) & 0xffffu) + half + uint32_t(v) * FRT_VIEW_B);
+        };
+        auto read8 = [&](const int c, u32x2 (&sa)[4], u32x2 (&sb)[4]) {
+            const uint32_t pa = slot_addr(c, 0), pb = slot_addr(c, 1);
+#if defined(FRT_ABL) && (FRT_ABL & 8) // measurement builds: no LDS reads
+#pragma unroll
+            for(int r = 0; r < 4; r++)
+            {
+                sa[r] = u32x2{pa + r, pb};
+                sb[r] = u32x2{pb + r, pa};
+            }
+            return;
+#endif
+#pragma unroll
+            for(int r = 0; r < 4; r++)
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(sa[r]) : "v"(pa), "n"(r * FRT_PW * 8));
+#pragma unroll
+            for(int r = 0; r < 4; r++)
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(sb[r]) : "v"(pb), "n"(r * FRT_PW * 8));
+        };
+        auto reduce = [&](const int c, u32x2 (&sa)[4], u32x2 (&sb)[4], const bool more_in_flight) {
+            if(more_in_flight)
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]));
+            const uint32_t va[6] = {sa[0].x, sa[1].x, sa[2].x, sa[3].x, sa[0].y, sa[2].y}, vb[6] = {sb[0].x, sb[1].x, sb[2].x, sb[3].x, sb[0].y, sb[2].y};
+#if defined(FRT_ABL) && (FRT_ABL & 16) // measurement builds: LDS reads, one instruction per candidate instead of twelve
+            lo[c][0] = as_u16x2(as_u32(lo[c][0]) ^ va[0] ^ va[1] ^ va[2] ^ va[3] ^ va[4] ^ va[5] ^ vb[0] ^ vb[1] ^ vb[2] ^ vb[3] ^ vb[4] ^ vb[5] ^ sa[1].y ^ sa[3].y ^ sb[1].y ^ sb[3].y);
+            return;
+#endif
+#pragma unroll
+            for(int r = 0; r < 6; r++)
+            {
+                lo[c][r] = min3_bytes(lo[c][r], as_u16x2(va[r]), as_u16x2(vb[r]));
+                hi[c][r] = max3_bytes(hi[c][r], as_u16x2(va[r]), as_u16x2(vb[r]));
+            }
+        };
+#if defined(FRT_ABL) && (FRT_ABL & 2) // measurement builds: no reduction (barriers only)
+        half ^= 2u * FRT_VIEW_B;
+        continue;
+#endif
+        u32x2 qa[2][4], qb[2][4];
+        read8(0, qa[0], qb[0]);
+#pragma unroll
+        for(int c = 0; c < CPW; c++)
+        {
+            if(c + 1 < CPW)
+                read8(c + 1, qa[(c + 1) & 1], qb[(c + 1) & 1]);
+            reduce(c, qa[c & 1], qb[c & 1], c + 1 < CPW);
+        }
+        half ^= 2u * FRT_VIEW_B;
+    }
+    // E: 16·range + (FLT_MIN tap ? 1 : 0) per pixel (focus_map.hpp); a lane holds rows 4·wave … 4·wave + 3 of its column
+    const int ey0 = int(ty) * FRT_TH + 4 * wave;
+    const uint32_t ex = tx * FRT_TW + lane;
+#pragma unroll
+    for(int c = 0; c < CPW; c++)
+#pragma unroll
+        for(int u = 0; u < 2; u++)
+        {
+            const u16x2 d0 = hi[c][2 * u] - lo[c][2 * u], d1 = hi[c][2 * u + 1] - lo[c][2 * u + 1], db = hi[c][4 + u] - lo[c][4 + u];
+            // (row 0, row 1) pairs per channel: low halves = R, high halves = G of the two rows
+            const u16x2 dr = as_u16x2(__builtin_amdgcn_perm(as_u32(d1), as_u32(d0), 0x05040100u)), dg = as_u16x2(__builtin_amdgcn_perm(as_u32(d1), as_u32(d0), 0x07060302u));
+            const u16x2 dmax = __builtin_elementwise_max(__builtin_elementwise_max(dr, dg), db);
+            const u16x2 hr = as_u16x2(__builtin_amdgcn_perm(as_u32(hi[c][2 * u + 1]), as_u32(hi[c][2 * u]), 0x05040100u));
+            const u16x2 hg = as_u16x2(__builtin_amdgcn_perm(as_u32(hi[c][2 * u + 1]), as_u32(hi[c][2 * u]), 0x07060302u));
+            const u16x2 hmin = __builtin_elementwise_min(__builtin_elementwise_min(hr, hg), hi[c][4 + u]);
+            const u16x2 nz = __builtin_elementwise_min(as_u16x2(as_u32(dmax) | as_u32(hmin)), as_u16x2(0x00010001u));
+            const uint32_t enc = (as_u32(dmax) << 4) + (0x00010001u - as_u32(nz)); // per half: 16·range ≤ 4080, no carry
+            const int ey = ey0 + 2 * u;
+            uint16_t *dst = w.E + ((size_t)(group * CPW + c) * w.He_p + ey) * w.We_p + ex;
+            if(ey < w.He_p) // wave-uniform: the last tile row of an image whose extended height is not a multiple of the tile's
+                dst[0] = static_cast<uint16_t>(enc);
+            if(ey + 1 < w.He_p)
+                dst[w.We_p] = static_cast<uint16_t>(enc >> 16);
+        }
+    } // work items
 }
 
 // 64-bit readlane (lane index uniform)

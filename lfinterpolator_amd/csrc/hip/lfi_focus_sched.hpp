@@ -11,7 +11,10 @@ namespace {
 
 // the factored estimate (focus_factored.hpp): carve the workspace, then plan → pad → E → exact keys → pick.
 // Returns LFI_OK with *done = false when the padded planes would be unreasonably large (the caller takes another variant).
-int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
+// direct_range: the range pass by focus_range (every use loads its own samples: the default); false = variant "factored_staged": by
+// focus_range_t where it applies (round 5: samples unpacked once into LDS — bit-exact, the second implementation in the parity tests, and
+// not faster yet: profiles/r05_notes.md)
+int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool direct_range)
 {
     *done = false;
     const int W = ctx->width, H = ctx->height, rx = ctx->radius[0], ry = ctx->radius[1];
@@ -46,9 +49,38 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     w.Py = Sy + ry;
     w.Wp = (w.Px + std::max(W + Sx + rx, w.We_p - rx + Sx) + 3) / 4 * 4;
     w.Hp = w.Py + std::max(H + Sy + ry, w.He_p - ry + Sy);
-    const size_t pad_bytes = sizeof(uint32_t) * (size_t)ctx->n_focus_ids * w.Hp * w.Wp;
+    // (+ FRT_PR + 16 rows of slack behind the last plane: focus_range_t fetches whole patches, also for the rows of its last tiles that
+    // lie below the extended image)
+    const size_t pad_bytes = sizeof(uint32_t) * ((size_t)ctx->n_focus_ids * w.Hp + lfi::FRT_PR + 16) * w.Wp;
     if(pad_bytes > ((size_t)16 << 30))
         return LFI_OK;
+    // Can the range pass unpack its samples once into LDS (focus_range_t)?  Within every group of CPW consecutive candidates a view's integer
+    // shifts — floor(f_i · offset), the device's own arithmetic (focus_plan_shifts) — must span at most FRT_MAX_DX pixels and FRT_MAX_DY rows:
+    // groups of 8 candidates if that holds, else groups of 4, else focus_range.  Typed loads address the planes with 32 bits.
+    int range_cpw = 0;
+    if(!direct_range && pad_bytes < ((size_t)1 << 32))
+        for(int cpw : {8, 4})
+        {
+            bool fits = true;
+            for(size_t k = 0; k < ctx->h_focus_offsets.size() && fits; k++)
+                for(int i0 = 0; i0 < lfi::FOCUS_STEPS && fits; i0 += cpw)
+                {
+                    int lo[2] = {INT32_MAX, INT32_MAX}, hi[2] = {INT32_MIN, INT32_MIN};
+                    for(int i = i0; i < i0 + cpw; i++)
+                    {
+                        const float f = std::fmaf(step, static_cast<float>(i), ctx->focus);
+                        const int sx = static_cast<int>(std::floor(static_cast<double>(f) * static_cast<double>(ctx->h_focus_offsets[k].x)));
+                        const int sy = static_cast<int>(std::floor(static_cast<double>(f) * static_cast<double>(ctx->h_focus_offsets[k].y)));
+                        lo[0] = std::min(lo[0], sx), hi[0] = std::max(hi[0], sx), lo[1] = std::min(lo[1], sy), hi[1] = std::max(hi[1], sy);
+                    }
+                    fits = hi[0] - lo[0] <= lfi::FRT_MAX_DX && hi[1] - lo[1] <= lfi::FRT_MAX_DY;
+                }
+            if(fits)
+            {
+                range_cpw = cpw;
+                break;
+            }
+        }
     size_t at = 0;
     auto carve = [&](size_t bytes) {
         const size_t here = at;
@@ -71,6 +103,7 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     const size_t o_E = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * (size_t)w.He_p * w.We_p);
     const size_t o_K = carve(sizeof(uint16_t) * lfi::FOCUS_STEPS * (size_t)H * W);
     const size_t o_deltas = carve(sizeof(int64_t) * lfi::FOCUS_STEPS * lfi::FOCUS_MAX_IDS);
+    const size_t o_patches = carve(sizeof(lfi::FocusPatch) * (lfi::FOCUS_STEPS / 4) * lfi::FOCUS_MAX_IDS);
     const size_t o_pad = carve(pad_bytes);
     if(ctx->focus_ws_bytes < at) // a larger workspace serves smaller geometries too
     {
@@ -101,6 +134,7 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     w.K = reinterpret_cast<uint16_t *>(base + o_K);
     w.deltas = reinterpret_cast<int64_t *>(base + o_deltas);
     w.pad = reinterpret_cast<uint32_t *>(base + o_pad);
+    lfi::FocusPatch *patches = reinterpret_cast<lfi::FocusPatch *>(base + o_patches);
     // Two streams: the plan and the flagged-pair passes are small, latency-bound kernels; they run beside the padded copy
     // and the range pass (bandwidth / VALU bound) instead of in front of them.
     //   main:  plan_shifts ─┬─ pad ─┬─ range ──────────────────────────┬──────────────┬─ pick (→ filter, by the caller)
@@ -119,6 +153,10 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     hipStream_t aux = ctx->aux_stream;
     // host launch order = the critical path first: the main stream's kernels are enqueued before the side stream's
     hipLaunchKernelGGL(lfi::focus_plan_shifts, dim3(1), dim3(1024), 0, st, a, w);
+    if(range_cpw == 8)
+        hipLaunchKernelGGL(lfi::focus_plan_patches<8>, dim3(lfi::FOCUS_STEPS / 8), dim3(32), 0, st, a, w, patches);
+    else if(range_cpw == 4)
+        hipLaunchKernelGGL(lfi::focus_plan_patches<4>, dim3(lfi::FOCUS_STEPS / 4), dim3(32), 0, st, a, w, patches);
     LFI_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
     if(pad_kept && ctx->pad_version != 0) // (a reallocated workspace cleared pad_version)
     {
@@ -139,6 +177,20 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done)
     }
     LFI_HIP(ctx, hipEventRecord(ctx->ev_pad, st));
     const uint32_t tiles_x = uint32_t(w.We_p / 256), tiles_y = uint32_t(w.He_p / 4);
+    if(range_cpw)
+    {
+        const uint32_t groups = uint32_t(lfi::FOCUS_STEPS / range_cpw);
+        const uint32_t ttx = uint32_t(w.We_p / lfi::FRT_TW), tty = uint32_t((w.He_p + lfi::FRT_TH - 1) / lfi::FRT_TH);
+        const int striped = ttx >= 8;
+        const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(ttx, tty, groups) : ttx * tty * groups;
+        // persistent: one workgroup per CU (it owns the whole LDS), a multiple of 8 so that a workgroup's work items stay on its XCD
+        const uint32_t grid = std::min(nblocks, uint32_t(std::max(ctx->cu_count / 8 * 8, 8)));
+        if(range_cpw == 8)
+            hipLaunchKernelGGL(lfi::focus_range_t<8>, dim3(grid), dim3(64 * (lfi::FRT_NW + lfi::FRT_LW)), 0, st, a, w, patches, uint32_t(pad_bytes), nblocks, striped);
+        else
+            hipLaunchKernelGGL(lfi::focus_range_t<4>, dim3(grid), dim3(64 * (lfi::FRT_NW + lfi::FRT_LW)), 0, st, a, w, patches, uint32_t(pad_bytes), nblocks, striped);
+    }
+    else
     {
         constexpr int CPW = 4, GROUPS = lfi::FOCUS_STEPS / CPW;
         const int striped = tiles_x >= 8;

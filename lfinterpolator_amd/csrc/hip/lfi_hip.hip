@@ -790,8 +790,8 @@ int lfi_focus_map(lfi_ctx *ctx)
     const bool lds_fits = 128 + 2 * ctx->radius[0] + 2 * lfi::FOCUS_LDS_SLACK <= lfi::FOCUS_LDS_ROW;
     // "factored" (default): W and H must fit the 16-bit column / row lists
     bool done = false;
-    if(ctx->focus_variant == 0 && ctx->width <= 65535 && ctx->height <= 65535)
-        if(int rc = launch_focus_factored(ctx, a, &done))
+    if((ctx->focus_variant == 0 || ctx->focus_variant == 4) && ctx->width <= 65535 && ctx->height <= 65535)
+        if(int rc = launch_focus_factored(ctx, a, &done, ctx->focus_variant != 4))
             return rc;
     if(done)
         ;
@@ -1284,7 +1284,7 @@ const char *lfi_list_variants(int method)
     if(method == LFI_METHOD_STD)
         return std_.c_str();
     if(method == LFI_KERNEL_FOCUS_ESTIMATE)
-        return "factored,lds,packed_p2,plain";
+        return "factored,lds,packed_p2,plain,factored_staged";
     return "";
 }
 
@@ -1323,13 +1323,13 @@ int lfi_set_variant(lfi_ctx *ctx, int method, const char *name)
     }
     else if(method == LFI_KERNEL_FOCUS_ESTIMATE)
     {
-        static const char *const names[] = {"factored", "lds", "packed_p2", "plain"};
+        static const char *const names[] = {"factored", "lds", "packed_p2", "plain", "factored_staged"};
         if(is_auto)
         {
             ctx->focus_variant = 0;
             return LFI_OK;
         }
-        for(int i = 0; i < 4; i++)
+        for(int i = 0; i < 5; i++)
             if(std::strcmp(name, names[i]) == 0)
             {
                 ctx->focus_variant = i;
