@@ -512,16 +512,19 @@ __global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const Foc
 // L1's tag rate; round 4's LDS-staged variant removed the L1 and kept the v_perm's (VALU-paced, the same time).  What the unit probes of
 // round 5 say (tools/probe_range_units.hip, profiles/r05_range_unit_probes.txt): v_pk_minimum3 / maximum3_f16 and v_perm_b32 issue every 5
 // cycles; LDS reads need NATURAL alignment (a ds_read_b64 at a 4-byte boundary runs 20 times slower), so samples addressed per pixel want
-// one 8-byte slot per pixel; the texture path unpacks for free — buffer_load_format_d16_xyzw through a descriptor of format 8_8_8_8 UINT
-// returns an RGBA8 pixel as four u16 in two registers, from any byte address.
+// one 8-byte slot per pixel.
 //
-// So: focus_pad stores the BLUE of the pixel one row below in the (unused) alpha byte; a typed load of a padded pixel then IS the slot
-// [R, G | B, B'] and goes to LDS with one ds_write_b64.  A lane owns one column and TWO row pairs of the tile; for the pair (y, y + 1) it
-// reads slot(y) whole and the [R, G] half of slot(y + 1): the three registers (R0,G0), (R1,G1), (B0,B1) — six bytes in u16 lanes, no
-// instruction spent on widening — and reduces two views per v_pk_minimum3 / maximum3_f16: 1.5 vector instructions per (pixel, candidate,
-// view) where focus_range issues 3.  A workgroup = 64 columns × 16 rows of CPW consecutive candidates; per step it stages the patches
-// of TWO views (each the tile plus the span of the group's shifts: at most 96 × 34 pixels) and every staged pixel serves CPW candidates.
-// Host-checked preconditions (launch_focus_factored; else focus_range): within a group a view's shifts span at most 32 pixels and 18 rows.
+// So: focus_pad stores the BLUE of the pixel one row below in the (unused) alpha byte, and a padded pixel widens to the slot
+// [R, G | B, B'] of four u16 with two v_perm_b32 — ONCE per staged pixel, by waves that do nothing else.  A reducing lane owns one column
+// and TWO row pairs of the tile; for the pair (y, y + 1) it reads slot(y) and slot(y + 1) and uses the three registers (R0,G0), (R1,G1),
+// (B0,B1) — six bytes in u16 lanes, no instruction spent on widening — and reduces two views per v_pk_minimum3 / maximum3_f16: 1.5 vector
+// instructions per (pixel, candidate, view) where focus_range issues 3.  A workgroup = 64 columns × 32 rows of CPW consecutive candidates;
+// per step it holds the patches of TWO views (each the tile plus the span of the group's shifts: at most 96 × 50 pixels) and every staged
+// pixel serves CPW candidates.  Host-checked preconditions (launch_focus_factored; else focus_range): within a group a view's shifts span
+// at most 32 pixels and 18 rows.  What was tried on the way (profiles/r05_notes.md): typed loads that unpack for free
+// (buffer_load_format_d16_xyzw, format 8_8_8_8 UINT: exact from any byte address, but 16 cycles per wave-load of ONE pixel per lane), every
+// wave loading and reducing in turn (the phases added up), one workgroup per tile × group (a workgroup that owns the LDS cannot overlap
+// its successor's start-up: 2.5 → 1.8 ms when made persistent).
 constexpr int FRT_TW = 64;                          // tile: extended columns (one per lane); rows: four per wave
 constexpr int FRT_NW = 8, FRT_TH = 4 * FRT_NW;      // waves per workgroup, tile rows
 constexpr int FRT_MAX_DX = 32, FRT_MAX_DY = 18;     // the largest span of a view's shifts within a candidate group
@@ -538,11 +541,6 @@ struct FocusPatch
     uint32_t d[4];     // per candidate c: byte offset of its samples inside the patch, (dy·FRT_PW + dx)·8, u16 pairs (c even: low half)
     uint32_t unused[2];
 };
-
-typedef _Float16 frt_h4 __attribute__((ext_vector_type(4)));
-typedef int frt_i4 __attribute__((ext_vector_type(4)));
-// buffer_load_format_d16_xyzw (the compiler tracks its vmcnt like any load's)
-__device__ frt_h4 frt_load_format_d16_xyzw(frt_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f16");
 
 // one thread per (group, view slot); after focus_plan_shifts
 template <int CPW>
@@ -576,6 +574,9 @@ __global__ void __launch_bounds__(32) focus_plan_patches(const KernelArgs a, con
 // least that wide) and row pairs ≡ L >> 1 (mod 2) of its "extra" part (columns 64 + (lane & 31), row 2·pair + (lane >> 5): all 32 columns
 // whatever the patch's width — columns beyond it land in slots nobody reads).
 constexpr int FRT_LW = 4; // loading waves
+// At most 136 registers per lane (tests/test_abi_library.py checks the code object): three waves per SIMD then leave room for ONE wave of
+// focus_flagged (100 registers, no LDS) on every SIMD — the flagged passes run BESIDE this kernel on the side stream, as they ran beside focus_range; with
+// 3 × 168 registers taken they queued behind it and the focus map took as long as before (profiles/r05_notes.md).
 template <int CPW>
 __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const KernelArgs a, const FocusWork w, const FocusPatch *plans, const uint32_t pad_bytes,
                                                                            const uint32_t nblocks, const int striped)
@@ -611,89 +612,136 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
         const int lw = wave - FRT_NW, v = lw & 1, par = lw >> 1;
         const uint32_t row_b = uint32_t(w.Wp) * 4u;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(w.pad, 0, int(pad_bytes), 0x00020000);
-        const int v_main = (lane >> 4) * int(row_b) + (lane & 15) * 16, v_extra = (lane >> 3) * int(row_b) + 4 * FRT_TW + (lane & 7) * 16;
+        const int v_main = (lane >> 4) * int(row_b) + (lane & 15) * 16;
         constexpr int MAIN_N = ((FRT_PR + 3) / 4 + 1) / 2, EXTRA_N = ((FRT_PR + 7) / 8 + 1) / 2; // row blocks of one parity
-        constexpr int MAIN_SURE = FRT_TH / 8, EXTRA_SURE = FRT_TH / 16;                           // … that every patch has
+        constexpr int MAIN_SURE = FRT_TH / 8;                                                     // … that every patch has
         uint8_t *const st_main = lds + v * FRT_VIEW_B + ((4 * par + (lane >> 4)) * FRT_PW + 4 * (lane & 15)) * 8;
-        uint8_t *const st_extra = lds + v * FRT_VIEW_B + ((8 * par + (lane >> 3)) * FRT_PW + FRT_TW + 4 * (lane & 7)) * 8;
-        const bool extra_tail_ok = 8 * (2 * (EXTRA_N - 1) + par) + (lane >> 3) < FRT_PR_LDS; // the last extra block may reach below the slots
-        uint32_t tile_off = 0;
-        focus_const_u32_ptr plan_words = nullptr;
-        // Two register sets: the loads of step s + 1 are issued BEFORE the slots of step s are stored, so the texture path never idles while
-        // a wave waits for its last load and stores.
+        // The "extra" part is as wide as the patch needs it — 2, 4 or 8 quads of pixels, i.e. blocks of 32, 16 or 8 rows per wave-load (most
+        // views' shifts span few columns: a third of all stored slots lay beyond their patches with a fixed width of 8 quads)
+        struct Step // one step of one work item, as the loading wave sees it
+        {
+            uint32_t b;        // work item
+            int k;             // first view of the step's pair
+            uint32_t tile_off; // byte offset of the tile's first extended pixel relative to extended (0, 0) (modular)
+            focus_const_u32_ptr plan_words;
+            bool valid;
+        };
+        auto first_step_of = [&](uint32_t b) {
+            Step st{b, 0, 0u, nullptr, false};
+            for(; st.b < nblocks; st.b += gridDim.x)
+            {
+                uint32_t tx, ty, group;
+                if(!work_item(st.b, tx, ty, group))
+                    continue;
+                st.tile_off = uint32_t((int(ty) * FRT_TH - a.radius_y) * w.Wp + (int(tx) * FRT_TW - a.radius_x)) * 4u;
+                st.plan_words = (focus_const_u32_ptr)(uintptr_t)(plans + group * FOCUS_MAX_IDS);
+                st.valid = true;
+                break;
+            }
+            return st;
+        };
+        auto next_step = [&](const Step &st) {
+            if(st.k + 2 < n_ids)
+            {
+                Step nx = st;
+                nx.k += 2;
+                return nx;
+            }
+            return first_step_of(st.b + gridDim.x);
+        };
+        struct Geo // what a fetched step's stores need to know
+        {
+            uint32_t pr; // rows of the patch
+            int sh;      // extra part: log2 of its quads per row (1, 2, 3), 0: no extra columns
+        };
+        // Two register sets: the loads of step s + 1 — of the NEXT work item behind an item's last step — are issued BEFORE the slots of step
+        // s are stored, so the texture path never idles while a wave waits for its last load and stores.
         u32x4 mA[MAIN_N], eA[EXTRA_N], mB[MAIN_N], eB[EXTRA_N];
-        uint32_t prA = 0, prB = 0;
-        auto fetch = [&](const int k, u32x4 (&m)[MAIN_N], u32x4 (&e)[EXTRA_N], uint32_t &pr) {
-            const int kv = min(k + v, n_ids - 1); // an odd tail reduces the last view twice: no minimum or maximum changes
-            const focus_const_u32_ptr pl = plan_words + kv * 8;
-            const uint32_t src = pl[0] + tile_off;
-            pr = pl[1] >> 16;
+        Geo gA{0, 0}, gB{0, 0};
+        auto fetch = [&](const Step &st, u32x4 (&m)[MAIN_N], u32x4 (&e)[EXTRA_N], Geo &g) {
+            const int kv = min(st.k + v, n_ids - 1); // an odd tail reduces the last view twice: no minimum or maximum changes
+            const focus_const_u32_ptr pl = st.plan_words + kv * 8;
+            const uint32_t src = pl[0] + st.tile_off;
+            g.pr = pl[1] >> 16;
+            const uint32_t ew = (pl[1] & 0xffffu) - FRT_TW;
+            g.sh = ew == 0 ? 0 : ew <= 8 ? 1 : ew <= 16 ? 2 : 3;
 #if defined(FRT_ABL) && (FRT_ABL & 1) // measurement builds: no loads (the slots get whatever the registers hold)
 #pragma unroll
             for(int i = 0; i < MAIN_N; i++)
-                m[i] = u32x4{src + i, pr, src, pr};
+                m[i] = u32x4{src + i, g.pr, src, g.pr};
 #pragma unroll
             for(int i = 0; i < EXTRA_N; i++)
-                e[i] = u32x4{src, pr + i, pr, src};
+                e[i] = u32x4{src, g.pr + i, g.pr, src};
             return;
 #endif
 #pragma unroll
             for(int i = 0; i < MAIN_N; i++)
-                if(i < MAIN_SURE || uint32_t(4 * (2 * i + par)) < pr) // wave-uniform: the block's first row
+                if(i < MAIN_SURE || uint32_t(4 * (2 * i + par)) < g.pr) // wave-uniform: the block's first row
                     m[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_main, int(src + uint32_t(4 * (2 * i + par)) * row_b), 0);
+            if(g.sh)
+            {
+                const int rows = 64 >> g.sh; // rows per block
+                const int v_extra = (lane >> g.sh) * int(row_b) + 4 * FRT_TW + (lane & ((1 << g.sh) - 1)) * 16;
 #pragma unroll
-            for(int i = 0; i < EXTRA_N; i++)
-                if(i < EXTRA_SURE || uint32_t(8 * (2 * i + par)) < pr)
-                    e[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_extra, int(src + uint32_t(8 * (2 * i + par)) * row_b), 0);
+                for(int i = 0; i < EXTRA_N; i++)
+                    if(uint32_t(rows * (2 * i + par)) < g.pr)
+                        e[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_extra, int(src + uint32_t(rows * (2 * i + par)) * row_b), 0);
+            }
         };
+        // A lane's four slots are 32 contiguous bytes, stored by two ds_write_b128; the 8 lanes a 16-byte store serves together would hit
+        // every bank twice if all of them stored their lower half first (lanes l and l + 4 are 128 bytes apart: 23 % of all LDS cycles were
+        // conflicts) — so lanes with bit 2 set store their UPPER half first: the halves of 8 neighbouring lanes then tile all 32 banks.
+        const bool upper_first = (lane & 4) != 0;
+        const int first_off = upper_first ? 16 : 0;
         auto put = [&](uint8_t *const dst, const u32x4 px) { // four padded pixels [R,G,B,B'] → four slots [R,G | B,B'] of u16
+            const uint32_t p0 = upper_first ? px.z : px.x, p1 = upper_first ? px.w : px.y, p2 = upper_first ? px.x : px.z, p3 = upper_first ? px.y : px.w;
             u32x4 s0, s1;
-            s0.x = __builtin_amdgcn_perm(0u, px.x, 0x0c010c00u), s0.y = __builtin_amdgcn_perm(0u, px.x, 0x0c030c02u);
-            s0.z = __builtin_amdgcn_perm(0u, px.y, 0x0c010c00u), s0.w = __builtin_amdgcn_perm(0u, px.y, 0x0c030c02u);
-            s1.x = __builtin_amdgcn_perm(0u, px.z, 0x0c010c00u), s1.y = __builtin_amdgcn_perm(0u, px.z, 0x0c030c02u);
-            s1.z = __builtin_amdgcn_perm(0u, px.w, 0x0c010c00u), s1.w = __builtin_amdgcn_perm(0u, px.w, 0x0c030c02u);
-            *reinterpret_cast<u32x4 *>(dst) = s0;
-            *reinterpret_cast<u32x4 *>(dst + 16) = s1;
+            s0.x = __builtin_amdgcn_perm(0u, p0, 0x0c010c00u), s0.y = __builtin_amdgcn_perm(0u, p0, 0x0c030c02u);
+            s0.z = __builtin_amdgcn_perm(0u, p1, 0x0c010c00u), s0.w = __builtin_amdgcn_perm(0u, p1, 0x0c030c02u);
+            s1.x = __builtin_amdgcn_perm(0u, p2, 0x0c010c00u), s1.y = __builtin_amdgcn_perm(0u, p2, 0x0c030c02u);
+            s1.z = __builtin_amdgcn_perm(0u, p3, 0x0c010c00u), s1.w = __builtin_amdgcn_perm(0u, p3, 0x0c030c02u);
+            *reinterpret_cast<u32x4 *>(dst + first_off) = s0;
+            *reinterpret_cast<u32x4 *>(dst + (16 - first_off)) = s1;
         };
-        auto store = [&](const u32x4 (&m)[MAIN_N], const u32x4 (&e)[EXTRA_N], const uint32_t pr) {
+        auto store = [&](const u32x4 (&m)[MAIN_N], const u32x4 (&e)[EXTRA_N], const Geo &g) {
             // (every wave has passed the previous barrier: the reducing waves are done with this half, which held the step before the one they reduce now)
 #pragma unroll
             for(int i = 0; i < MAIN_N; i++)
-                if(i < MAIN_SURE || uint32_t(4 * (2 * i + par)) < pr)
+                if(i < MAIN_SURE || uint32_t(4 * (2 * i + par)) < g.pr)
                     put(st_main + half + 8 * i * FRT_PW * 8, m[i]);
+            if(g.sh)
+            {
+                const int rows = 64 >> g.sh;
+                const int row0 = rows * par + (lane >> g.sh); // this lane's row in the wave's first block
+                uint8_t *const st_extra = lds + v * FRT_VIEW_B + half + (row0 * FRT_PW + FRT_TW + 4 * (lane & ((1 << g.sh) - 1))) * 8;
 #pragma unroll
-            for(int i = 0; i < EXTRA_N; i++)
-                if(i < EXTRA_SURE || uint32_t(8 * (2 * i + par)) < pr)
-                {
-                    if(i + 1 < EXTRA_N || extra_tail_ok)
-                        put(st_extra + half + 16 * i * FRT_PW * 8, e[i]);
-                }
+                for(int i = 0; i < EXTRA_N; i++)
+                    if(uint32_t(rows * (2 * i + par)) < g.pr && row0 + 2 * rows * i < FRT_PR_LDS) // (a block may reach below the rows of slots)
+                        put(st_extra + 2 * rows * i * FRT_PW * 8, e[i]);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's slots are in LDS
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             half ^= 2u * FRT_VIEW_B;
         };
-        for(uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x)
+        Step sA = first_step_of(blockIdx.x);
+        if(!sA.valid)
+            return;
+        fetch(sA, mA, eA, gA);
+        for(;;)
         {
-            uint32_t tx, ty, group;
-            if(!work_item(b, tx, ty, group))
-                continue;
-            // byte offset of the tile's first extended pixel relative to extended (0, 0) (negative near the top / left: modular, added to FocusPatch::src)
-            tile_off = uint32_t((int(ty) * FRT_TH - a.radius_y) * w.Wp + (int(tx) * FRT_TW - a.radius_x)) * 4u;
-            plan_words = (focus_const_u32_ptr)(uintptr_t)(plans + group * FOCUS_MAX_IDS);
-            fetch(0, mA, eA, prA);
-            for(int k = 0; k < n_ids; k += 4)
-            {
-                if(k + 2 < n_ids)
-                    fetch(k + 2, mB, eB, prB);
-                store(mA, eA, prA);
-                if(k + 2 < n_ids)
-                {
-                    if(k + 4 < n_ids)
-                        fetch(k + 4, mA, eA, prA);
-                    store(mB, eB, prB);
-                }
-            }
+            const Step sB = next_step(sA);
+            if(sB.valid)
+                fetch(sB, mB, eB, gB);
+            store(mA, eA, gA);
+            if(!sB.valid)
+                break;
+            sA = next_step(sB);
+            if(sA.valid)
+                fetch(sA, mA, eA, gA);
+            store(mB, eB, gB);
+            if(!sA.valid)
+                break;
         }
         return;
     }
@@ -740,15 +788,6 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
         };
         auto read8 = [&](const int c, u32x2 (&sa)[4], u32x2 (&sb)[4]) {
             const uint32_t pa = slot_addr(c, 0), pb = slot_addr(c, 1);
-#if defined(FRT_ABL) && (FRT_ABL & 8) // measurement builds: no LDS reads
-#pragma unroll
-            for(int r = 0; r < 4; r++)
-            {
-                sa[r] = u32x2{pa + r, pb};
-                sb[r] = u32x2{pb + r, pa};
-            }
-            return;
-#endif
 #pragma unroll
             for(int r = 0; r < 4; r++)
                 asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(sa[r]) : "v"(pa), "n"(r * FRT_PW * 8));
@@ -762,10 +801,6 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
             else
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]));
             const uint32_t va[6] = {sa[0].x, sa[1].x, sa[2].x, sa[3].x, sa[0].y, sa[2].y}, vb[6] = {sb[0].x, sb[1].x, sb[2].x, sb[3].x, sb[0].y, sb[2].y};
-#if defined(FRT_ABL) && (FRT_ABL & 16) // measurement builds: LDS reads, one instruction per candidate instead of twelve
-            lo[c][0] = as_u16x2(as_u32(lo[c][0]) ^ va[0] ^ va[1] ^ va[2] ^ va[3] ^ va[4] ^ va[5] ^ vb[0] ^ vb[1] ^ vb[2] ^ vb[3] ^ vb[4] ^ vb[5] ^ sa[1].y ^ sa[3].y ^ sb[1].y ^ sb[3].y);
-            return;
-#endif
 #pragma unroll
             for(int r = 0; r < 6; r++)
             {
@@ -777,14 +812,18 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
         half ^= 2u * FRT_VIEW_B;
         continue;
 #endif
-        u32x2 qa[2][4], qb[2][4];
-        read8(0, qa[0], qb[0]);
+        // (one set of read registers: the next candidate's reads are issued once this one's are consumed — the other waves of the SIMD cover
+        // the LDS latency; a second set would not fit the register budget above)
+        u32x2 qa[4], qb[4];
 #pragma unroll
         for(int c = 0; c < CPW; c++)
         {
-            if(c + 1 < CPW)
-                read8(c + 1, qa[(c + 1) & 1], qb[(c + 1) & 1]);
-            reduce(c, qa[c & 1], qb[c & 1], c + 1 < CPW);
+            read8(c, qa, qb);
+            reduce(c, qa, qb, false);
+            // (pins this candidate's reduction in front of the next candidate's reads: left to the scheduler the reduction sinks below them
+            // and the reads take a second set of 16 registers)
+            asm volatile("" : "+v"(lo[c][0]), "+v"(lo[c][1]), "+v"(lo[c][2]), "+v"(lo[c][3]), "+v"(lo[c][4]), "+v"(lo[c][5]), "+v"(hi[c][0]), "+v"(hi[c][1]),
+                         "+v"(hi[c][2]), "+v"(hi[c][3]), "+v"(hi[c][4]), "+v"(hi[c][5]));
         }
         half ^= 2u * FRT_VIEW_B;
     }

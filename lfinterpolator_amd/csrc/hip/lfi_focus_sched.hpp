@@ -11,9 +11,8 @@ namespace {
 
 // the factored estimate (focus_factored.hpp): carve the workspace, then plan → pad → E → exact keys → pick.
 // Returns LFI_OK with *done = false when the padded planes would be unreasonably large (the caller takes another variant).
-// direct_range: the range pass by focus_range (every use loads its own samples: the default); false = variant "factored_staged": by
-// focus_range_t where it applies (round 5: samples unpacked once into LDS — bit-exact, the second implementation in the parity tests, and
-// not faster yet: profiles/r05_notes.md)
+// direct_range: the range pass by focus_range (rounds 1-4's kernel: every use loads and widens its own samples) even where focus_range_t
+// applies (variant "factored_direct": the second implementation in the parity tests, and the A/B partner)
 int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool direct_range)
 {
     *done = false;

@@ -791,7 +791,7 @@ int lfi_focus_map(lfi_ctx *ctx)
     // "factored" (default): W and H must fit the 16-bit column / row lists
     bool done = false;
     if((ctx->focus_variant == 0 || ctx->focus_variant == 4) && ctx->width <= 65535 && ctx->height <= 65535)
-        if(int rc = launch_focus_factored(ctx, a, &done, ctx->focus_variant != 4))
+        if(int rc = launch_focus_factored(ctx, a, &done, ctx->focus_variant == 4))
             return rc;
     if(done)
         ;
@@ -1284,7 +1284,7 @@ const char *lfi_list_variants(int method)
     if(method == LFI_METHOD_STD)
         return std_.c_str();
     if(method == LFI_KERNEL_FOCUS_ESTIMATE)
-        return "factored,lds,packed_p2,plain,factored_staged";
+        return "factored,lds,packed_p2,plain,factored_direct";
     return "";
 }
 
@@ -1323,7 +1323,7 @@ int lfi_set_variant(lfi_ctx *ctx, int method, const char *name)
     }
     else if(method == LFI_KERNEL_FOCUS_ESTIMATE)
     {
-        static const char *const names[] = {"factored", "lds", "packed_p2", "plain", "factored_staged"};
+        static const char *const names[] = {"factored", "lds", "packed_p2", "plain", "factored_direct"};
         if(is_auto)
         {
             ctx->focus_variant = 0;

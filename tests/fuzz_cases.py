@@ -137,7 +137,7 @@ def fuzz_focus(L, oc, n_cases: int, seed: int, log=None) -> list:
         ctx.set_grid(cols, rows, W, H)
         ctx.upload_grid(lf)
         ctx.set_params(hp)
-        for var in ("factored", "factored_staged", "plain", "lds"):
+        for var in ("factored", "factored_direct", "plain", "lds"):
             ctx.set_variant("FOCUS", var)
             ctx.focus_map()
             ctx.sync()

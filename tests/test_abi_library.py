@@ -108,6 +108,14 @@ def test_pipelined_kernels_use_no_scratch_and_the_counted_stores(native, tmp_pat
             kernels[name] = {}
         elif name and ":" in line and line.split(":")[0] in (".private_segment_fixed_size", ".vgpr_spill_count", ".sgpr_spill_count", ".vgpr_count"):
             kernels[name][line.split(":")[0]] = int(line.split(":")[1])
+    # focus_range_t (round 5): hand-counted lgkmcnt waits on its LDS reads (no scratch), and at most 136 registers per lane — three of its
+    # waves per SIMD must leave room for one wave of focus_flagged (at most 104), or the flagged passes queue behind the persistent kernel
+    range_t = [k for k in kernels if "focus_range_tI" in k]
+    assert len(range_t) == 2, sorted(kernels)
+    for k in range_t:
+        assert kernels[k][".private_segment_fixed_size"] == 0 and kernels[k][".vgpr_spill_count"] == 0 and kernels[k][".vgpr_count"] <= 136, (k, kernels[k])
+    flagged = [k for k in kernels if "focus_flagged" in k]
+    assert len(flagged) == 1 and kernels[flagged[0]][".vgpr_count"] <= 104, (flagged, kernels[flagged[0]] if flagged else None)
     pipelined = [k for k in kernels if any(s in k for s in ("blend_p3", "blend_planar", "blend_persist", "blend_wave", "blend_stdx", "blend_afs"))]
     assert sum("blend_afsI" in k for k in pipelined) == 2     # all-focus STD, every sample gathered once: three and four chunks
     assert sum("blend_stdxI" in k for k in pipelined) == 8    # fixed focus: one to four chunks of images, RGBA and planar views

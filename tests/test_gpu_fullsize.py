@@ -145,7 +145,7 @@ def test_config5_15x15_4k_bands(gpu, oracle_c):
 
     # the focus map: both estimate implementations agree everywhere, and equal the oracle on the bands
     maps = {}
-    for variant in ("factored", "factored_staged", "lds"):
+    for variant in ("factored", "factored_direct", "lds"):
         ctx.set_variant("FOCUS", variant)
         ctx.focus_map()
         ctx.focus_map()   # a second call reuses the workspace and the side stream
@@ -153,7 +153,7 @@ def test_config5_15x15_4k_bands(gpu, oracle_c):
         maps[variant] = (ctx.download_map(0), ctx.download_map(1))
     assert (maps["factored"][0] == maps["lds"][0]).all(), int((maps["factored"][0] != maps["lds"][0]).sum())
     assert (maps["factored"][1] == maps["lds"][1]).all()
-    assert (maps["factored_staged"][0] == maps["lds"][0]).all() and (maps["factored_staged"][1] == maps["lds"][1]).all()
+    assert (maps["factored_direct"][0] == maps["lds"][0]).all() and (maps["factored_direct"][1] == maps["lds"][1]).all()
     map0, map1 = maps["factored"]
     assert len(np.unique(map0[..., 0])) > 4
     ctx.set_variant("FOCUS", "auto")

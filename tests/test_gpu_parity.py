@@ -472,7 +472,7 @@ def test_focus_map_realistic_geometry(radius, gpu, oracle_c):
     ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
     want0 = oracle_c.focus_estimate(lf, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, threads=8)
     assert len(np.unique(want0)) > 8
-    for variant in ("factored", "factored_staged", "lds"):
+    for variant in ("factored", "factored_direct", "lds"):
         ctx.set_variant("FOCUS", variant)
         ctx.focus_map()
         ctx.sync()
