@@ -55,9 +55,11 @@ CONFIGS = {
 }
 
 
-def cpu_baseline(cfg, hp, threads: int, sample_views: int | None = None, budget_s: float = 12.0) -> dict:
+def cpu_baseline(cfg, hp, threads: int, sample_views: int | None = None, budget_s: float = 12.0, gpu_rows: dict | None = None) -> dict:
     """The oracle's scalar STD blend on the same workload, on `threads` host cores: whole steps (all views), or — `sample_views` — the
-    first few full-frame views of the step (the single-threaded leg renders min(V, 4) views)."""
+    first few full-frame views of the step (the single-threaded leg renders min(V, 4) views).
+    gpu_rows = {view: (y0, y1, rows of the view the timed GPU launches rendered)}: while the oracle and its host copy of the grid are at
+    hand, also state how the TEN_WM bytes compare with the oracle's model of the reference's half accumulators (M16): `ten_wm_vs_m16`."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle import lfi_oracle_c as oc
@@ -73,10 +75,19 @@ def cpu_baseline(cfg, hp, threads: int, sample_views: int | None = None, budget_
         oc.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, v0=0, v1=v, threads=threads)
         steps += 1
     dt = (time.perf_counter() - t0) / steps
-    return {"value": v / dt, "unit": "views/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} pass(es): {v} views of {W}x{H} from {n} images each, scalar fp32 FMA weighted mean "
-                      f"(oracle STD), {dt:.2f} s wall per pass, {dt * steps * threads:.0f} s of CPU work",
-            "gpix_per_s": v * W * H / dt / 1e9}
+    res = {"value": v / dt, "unit": "views/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+           "sample": f"{steps} pass(es): {v} views of {W}x{H} from {n} images each, scalar fp32 FMA weighted mean "
+                     f"(oracle STD), {dt:.2f} s wall per pass, {dt * steps * threads:.0f} s of CPU work",
+           "gpix_per_s": v * W * H / dt / 1e9}
+    if gpu_rows:
+        same = total = worst = 0
+        for view, (y0, y1, got) in gpu_rows.items():
+            want = oc.blend_ten(lf, hp.focused_offsets, hp.offsets, hp.weights, v0=view, v1=view + 1, rows=(y0, y1), threads=threads, model=oc.TEN_M16)[view, y0:y1]
+            d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+            same, total, worst = same + int((d == 0).sum()), total + d.size, max(worst, int(d.max()))
+        res["ten_wm_vs_m16"] = {"exact_match_fraction": same / total, "max_abs_diff_lsb": worst, "bytes_compared": total,
+                                "rows": {str(v): [y0, y1] for v, (y0, y1, _) in gpu_rows.items()}}
+    return res
 
 
 def b_alg(W, rows_in, n_images, rows_out, views):
@@ -148,6 +159,34 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         except Exception as e:
             out[section.__name__ + "_error"] = f"{type(e).__name__}: {e}"
 
+    def fixed_focus_sweep(ctx, cfg, key):
+        """A fixed-focus -f sweep (scripts/focusMapCompare.sh varies -f per run; loadGPUOffsets, src/interpolator.cu:226-246): 16 parameter
+        sets around the configuration's focus, lfi_set_params + lfi_render each, NO lfi_prepare — every render has new integer offsets, so the
+        derived planar copy keeps the per-image phases it was built with (stale: DESIGN.md 3) — per step, next to the same loop over ONE
+        parameter set (what lfi_set_params itself adds to a tuned launch).  TEN_WM in the bench's view layout, STD likewise."""
+        if layout != "rgba":
+            ctx.set_output_layout(layout)
+        sets = [L.build_params(cfg["cols"], cfg["rows"], cfg["W"], cfg["H"], cfg["traj"], f, 0.0, cfg["effect"], cfg["aspect"], cfg["views"])
+                for f in np.linspace(cfg["focus"] - 0.02, cfg["focus"] + 0.02, 16)]
+        centre = L.build_params(cfg["cols"], cfg["rows"], cfg["W"], cfg["H"], cfg["traj"], cfg["focus"], 0.0, cfg["effect"], cfg["aspect"], cfg["views"])
+        for method, suffix in (("TEN_WM", ""), ("STD", "_std")):
+            def loop(params):
+                for hp_f in params:
+                    ctx.set_params(hp_f)
+                    ctx.render(method)
+            ctx.set_params(centre)
+            ctx.prepare(method)
+            same = timed(ctx, lambda: loop([centre] * len(sets)), 1, warm=1, rounds=3) / len(sets)
+            loop(sets)                                                     # the copy's padding grows to the sweep's largest offset once
+            ms = timed(ctx, lambda: loop(sets), 1, warm=1, rounds=3) / len(sets)
+            e = entry(cfg, ms, cfg["views"], "lfi_set_params + " + ctx.last_kernel_name(),
+                      "per step of a 16-step fixed-focus sweep (-f ±0.02 around the configuration's): new offsets every render, the planar copy's phases stale",
+                      out_bpp=3 if layout != "rgba" else 4)
+            e["same_parameters_ms"] = same
+            out[f"{key}_fixed_focus_sweep_step{suffix}"] = e
+        ctx.set_params(centre)
+        ctx.set_output_layout("rgba")
+
     # ---- config 2: the reference-layout (RGBA) output, STD, the non-tensor wavefront kernel ---------------------------------------
     def config2():
         c2 = CONFIGS[2]
@@ -171,6 +210,8 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         ctx.set_variant("STD", "vfma")
         ms = timed(ctx, lambda: ctx.render("STD"), max(2, iters // 2), warm=1)
         out["config2_std_valu"] = entry(c2, ms, 64, ctx.last_kernel_name(), "the non-tensor wavefront kernel: one pass over the inputs, v_pk_fma_f32 chains, weights in SGPRs", flops_bound=True)
+        ctx.set_variant("STD", "auto")
+        fixed_focus_sweep(ctx, c2, "config2")
         ctx.close()
 
     guarded(config2)
@@ -247,6 +288,8 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         ms = timed(ctx, lambda: ctx.render("STD"), 2, warm=1, rounds=2)
         out["config5_fixed_focus_std_nontensor"] = entry(c5, ms, 64, ctx.last_kernel_name(), "the non-tensor wavefront kernel (v_pk_fma_f32 chains)", flops_bound=True)
         ctx.set_variant("STD", "auto")
+        fixed_focus_sweep(ctx, c5, "config5")
+        ctx.set_params(hp)
         # the focus sweep on a STRUCTURED light field: a texture seen at a piecewise-constant focus inside
         # [focus, focus + range], so that the estimated map is piecewise constant as on real scenes — on hash noise the map is noise and
         # the all-focus gathers touch one cache line per pixel (measured: 17 ms instead of ≈2 ms), which no real input does
@@ -558,6 +601,12 @@ def main() -> int:
     # cheap sanity check that the timed launches rendered something: alpha 255 everywhere, RGB not constant
     sample = ctx.download_view(0)[ctx.out_rows[0] + out_rows_n // 2, :64]
     assert (sample[:, 3] == 255).all() and sample[:, :3].std() > 0, "render produced no image"
+    gpu_rows = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2 and args.method == "TEN_WM" and args.shard == "views":
+        # 48 rows (top edge, middle, bottom edge) of three views of the timed launches, for cpu_baseline's ten_wm_vs_m16
+        gpu_rows = {}
+        for view, y0 in ((0, 0), (views_per_gpu // 2, HEIGHT // 2 - 8), (views_per_gpu - 1, HEIGHT - 16)):
+            gpu_rows[view] = (y0, y0 + 16, ctx.download_view(view)[y0:y0 + 16].copy())
 
     if rank == 0:
         value = total_views * args.steps / elapsed_max
@@ -633,7 +682,13 @@ def main() -> int:
                                 "algorithmic_flops_per_launch": f_alg, "hbm_frac_of_8000_gbs": achieved / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline and args.config == 2:
             threads = min(os.cpu_count() or 1, 16)
-            line["cpu_baseline"] = cpu_baseline(cfg, hp, threads)
+            line["cpu_baseline"] = cpu_baseline(cfg, hp, threads, gpu_rows=gpu_rows)
+            if "ten_wm_vs_m16" in line["cpu_baseline"]:
+                m16 = line["cpu_baseline"]["ten_wm_vs_m16"]
+                line["config"]["ten_wm_tolerance"] = ("u8 bytes within 1 LSB (= 3.9e-3 normalised) of M16, the oracle's model of the reference's half accumulators; "
+                                                      "pre-quantisation within 1e-3 normalised of the exact fp64 blend (tests/test_gpu_parity.py)")
+                line["config"]["ten_wm_exact_match_vs_m16"] = m16["exact_match_fraction"]
+                line["config"]["ten_wm_max_abs_diff_lsb_vs_m16"] = m16["max_abs_diff_lsb"]
             # the same scalar code on ONE thread, min(V, 4) full-frame views
             line["cpu_baseline_1thread"] = cpu_baseline(cfg, hp, 1, sample_views=4, budget_s=8.0)
 

@@ -82,6 +82,12 @@ struct lfi_ctx
     size_t param_staging_bytes = 0;
     hipEvent_t ev_param[2] = {nullptr, nullptr};
     int param_slot = 0;
+    // … and there are TWO copies of the arrays on the device: a replacement is copied into the idle one on the copy stream, beside the renders
+    // still running from the other (round 5: in stream order behind them it cost a fixed-focus sweep 22 µs per step, profiles/r05_notes.md)
+    size_t param_half_stride = 0;
+    int param_half = 0;
+    hipEvent_t ev_half_done[2] = {nullptr, nullptr}; // recorded on the compute stream when the context switches away from a half
+    bool half_done_recorded[2] = {false, false};
     size_t blob_off_w16 = 0, blob_weights_bytes = 0; // the four weight arrays inside the blob (what lfi_render_stream replaces per block)
     // lfi_render_stream: page-locked staging for two blocks' weight arrays, a second set of views, events
     uint8_t *stream_staging[2] = {nullptr, nullptr};
@@ -388,7 +394,15 @@ void free_params(lfi_ctx *c)
         (void)hipFree(c->param_blob);
     c->param_blob = nullptr;
     c->param_blob_bytes = 0;
+    c->param_half = 0;
+    c->half_done_recorded[0] = c->half_done_recorded[1] = false;
     c->have_params = false;
+}
+
+// the copy of the parameter arrays that launches enqueued from now on read
+uint8_t *param_base(const lfi_ctx *c)
+{
+    return static_cast<uint8_t *>(c->param_blob) + (size_t)c->param_half * c->param_half_stride;
 }
 
 void free_param_staging(lfi_ctx *c)
@@ -401,6 +415,9 @@ void free_param_staging(lfi_ctx *c)
         if(c->ev_param[i])
             (void)hipEventDestroy(c->ev_param[i]);
         c->ev_param[i] = nullptr;
+        if(c->ev_half_done[i])
+            (void)hipEventDestroy(c->ev_half_done[i]);
+        c->ev_half_done[i] = nullptr;
     }
     c->param_staging_bytes = 0;
 }

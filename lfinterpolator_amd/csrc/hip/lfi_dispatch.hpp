@@ -350,10 +350,14 @@ int next_sweep_direction(const lfi_ctx *c)
 
 // Make the planar copy of the inputs valid for a fixed-focus launch with the current parameters; returns false (and leaves the
 // launch on the RGBA planes) when the copy may not be used: inputs the library cannot track, absurd offsets.
-// tune: also make the copy's per-image phases fit the CURRENT integer offsets (every run then starts on a dword: ≈ 3–5 % faster
-// launches, tools/align_probe.py) — a rebuild.  lfi_prepare / lfi_benchmark ask for it; launch_blend asks once the same offsets have
-// been rendered a few times (the reference's 100-launch loop, a trajectory streamed at one focus), so a focus sweep — new offsets
-// every render — never pays a rebuild per render.
+// tune: also make the copy's per-image phases fit the CURRENT integer offsets (every 128-byte run of a tile then IS one cache line) — a
+// rebuild.  lfi_prepare / lfi_benchmark ask for it; launch_blend asks once the same offsets have been rendered LFI_RETUNE_AFTER times (the
+// reference's 100-launch loop, a trajectory streamed at one focus), so a fixed-focus sweep — new offsets every render — never pays a
+// rebuild per render.  What stale phases cost such a sweep (round 5, profiles/r05_pmc_sweep_summary.txt, fixed_focus_sweep_*.txt): the
+// launch takes 6–10 % longer (config 2: 137.6 → 151.2 µs, config 5: 1.44 → 1.53 ms) — twice the L1 tag accesses (a lane's 16-byte piece
+// straddles sectors, a run two lines) and 9 % more bytes from HBM (boundary lines shared with the neighbouring tiles) — against a rebuild
+// of 1.8 launches' time (0.25 ms at config 2): per-image phases cannot survive a change of -f (every image's offset moves by its own
+// amount), so for one render per parameter set the stale copy is the cheaper choice; `also.config*_fixed_focus_sweep_step` times it.
 // LFI_PLANAR_ALIGN: what the runs of the offsets in use are aligned to by the per-image phases — 128 (round 4): a tile's 128-byte run of
 // an image row is then exactly ONE cache line (no boundary sectors fetched with the neighbouring tiles: the launches of several chunks
 // over-fetched 10–19 %, profiles/r04_pmc_traffic_summary.txt); 4 = round 3's dword alignment.  Power of two, ≤ 128.
@@ -379,7 +383,7 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     if(valid && (!tune || tuned()))
         return true;
     if(c->inputs_released)
-        return valid; // nothing to rebuild from: the copy serves the offsets it was built for (untuned phases only cost 3–5 %), or the render is refused
+        return valid; // nothing to rebuild from: the copy serves the offsets it was built for (stale phases cost a launch 6–10 %), or the render is refused
     // the copy in place fits and only SOME images were replaced since it was brought up to date (lfi_upload_image, a partial fill): their
     // planes only — 1/N of a rebuild per image
     if(c->planar && c->planar_version != 0 && c->planar_reach >= reach && (int)c->planar_phase.size() == c->n &&
@@ -479,8 +483,8 @@ bool ensure_planar(lfi_ctx *c, bool tune = false)
     return true;
 }
 
-// launch_blend's policy for the rebuild above.  A rebuild re-converts the whole copy (0.25 ms at config 2, ≈ 3 ms at config 5) for a 3–5 %
-// gain per launch: it pays for itself after ≈ 40 launches.  So a render only retunes once the same integer offsets have been rendered
+// launch_blend's policy for the rebuild above.  A rebuild re-converts the whole copy (0.25 ms at config 2, ≈ 3 ms at config 5) for a 6–10 %
+// gain per launch (14 µs at config 2, 0.09 ms at config 5): it pays for itself after ≈ 20–30 launches.  So a render only retunes once the same integer offsets have been rendered
 // LFI_RETUNE_AFTER times (the reference's own loop is 100 launches over one parameter set, src/interpolator.cu:270-295; round 3 retuned
 // at the third launch, a net loss for short runs); lfi_prepare and lfi_benchmark retune at once, outside any render.
 constexpr unsigned LFI_RETUNE_AFTER = 32;

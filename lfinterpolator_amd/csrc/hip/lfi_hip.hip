@@ -566,6 +566,7 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
             {
                 LFI_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->param_staging[i]), total, hipHostMallocDefault));
                 LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_param[i], hipEventDisableTiming));
+                LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_half_done[i], hipEventDisableTiming));
             }
             ctx->param_staging_bytes = total;
         }
@@ -603,18 +604,32 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
 
     if(in_place)
     {
-        LFI_HIP(ctx, hipMemcpyAsync(ctx->param_blob, blob.data(), total, hipMemcpyHostToDevice, ctx->stream));
-        LFI_HIP(ctx, hipEventRecord(ctx->ev_param[ctx->param_slot], ctx->stream));
+        // into the device copy no launch reads any more, on the copy stream: beside the renders still running from the other copy.  Order:
+        // the launches that read the idle copy were all enqueued before the context switched away from it (ev_half_done, recorded then);
+        // launches enqueued from now on wait for this copy.
+        if(int rc = ensure_copy_stream(ctx))
+            return rc;
+        const int cur = ctx->param_half, next = cur ^ 1;
+        LFI_HIP(ctx, hipEventRecord(ctx->ev_half_done[cur], ctx->stream));
+        ctx->half_done_recorded[cur] = true;
+        if(ctx->half_done_recorded[next])
+            LFI_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_half_done[next], 0));
+        LFI_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(ctx->param_blob) + (size_t)next * ctx->param_half_stride, blob.data(), total, hipMemcpyHostToDevice,
+                                    ctx->copy_stream));
+        LFI_HIP(ctx, hipEventRecord(ctx->ev_param[ctx->param_slot], ctx->copy_stream));
+        LFI_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_param[ctx->param_slot], 0));
         ctx->param_slot ^= 1;
+        ctx->param_half = next;
     }
     else
     {
         free_params(ctx);
-        LFI_HIP(ctx, hipMalloc(&ctx->param_blob, total));
+        ctx->param_half_stride = (total + 255) / 256 * 256;
+        LFI_HIP(ctx, hipMalloc(&ctx->param_blob, 2 * ctx->param_half_stride));
         ctx->param_blob_bytes = total;
         LFI_HIP(ctx, hipMemcpy(ctx->param_blob, blob.data(), total, hipMemcpyHostToDevice));
     }
-    uint8_t *base = static_cast<uint8_t *>(ctx->param_blob);
+    uint8_t *base = param_base(ctx);
     ctx->d_focused = reinterpret_cast<lfi_int2 *>(base + off_focused);
     ctx->d_offsets = reinterpret_cast<lfi_float2 *>(base + off_offsets);
     ctx->d_w16 = reinterpret_cast<uint16_t *>(base + off_w16);
@@ -930,7 +945,7 @@ int lfi_render_stream(lfi_ctx *ctx, int method, int all_focus, const uint16_t *w
     if(int rc = join_uploads(ctx))
         return rc;
     const int n_blocks = (total_views + V - 1) / V;
-    uint8_t *dev_weights = static_cast<uint8_t *>(ctx->param_blob) + ctx->blob_off_w16;
+    uint8_t *dev_weights = param_base(ctx) + ctx->blob_off_w16;
     uint8_t *const vbuf[2] = {ctx->views, host_out ? ctx->views2 : ctx->views};
     uint8_t *const views_saved = ctx->views;
     int status = LFI_OK;
