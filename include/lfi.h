@@ -72,7 +72,10 @@ enum {
      * bit-exactness to rest on a measured property of the hardware. */
     LFI_FLAG_STD_ANALYTIC_BAND = 8u,
     /* Up to 64 images: the band of the measured bound (rounds 2-3's default) instead of the analytic one.  Same bytes. */
-    LFI_FLAG_STD_MEASURED_BAND = 16u
+    LFI_FLAG_STD_MEASURED_BAND = 16u,
+    /* Test hook of the band's self-check (lfi_std_band_info): behave as if the device had FAILED the measurement the measured bound
+     * rests on — STD launches over more than 64 images then take the analytic band.  Same bytes. */
+    LFI_FLAG_STD_BAND_PROBE_FAIL = 32u
 };
 
 #define LFI_MAX_IMAGES 256     /* MAX_IMAGES, src/kernels.cu:60 */
@@ -247,6 +250,23 @@ typedef struct lfi_memory {
     float derived_build_ms;
 } lfi_memory;
 int lfi_memory_info(lfi_ctx *ctx, lfi_memory *out);
+/* The band method's self-check (round 5).  STD over more than 64 images (Standard::process, src/kernels.cu:289-343, computed as fp16
+ * matrix-core sums + the exact fmaf chain inside a band around x.5) sizes that band with a bound on the matrix core's accumulation error
+ * that was MEASURED on gfx950 (a quarter ulp per addend).  The first such launch on a device therefore repeats the measurement there —
+ * chains of the MFMA instructions the kernels use over adversarial operand sets, exact sums on the host, once per device and process —
+ * and if any sum exceeds the budget every such launch on that device takes the analytic band instead (LFI_FLAG_STD_ANALYTIC_BAND's:
+ * same bytes, more sums recomputed).  This call runs the check if it has not run yet and reports it. */
+typedef struct lfi_std_band {
+    int32_t probed;           /* 1 once the device has been measured */
+    int32_t within_budget;    /* 1: every sum within N*2^-17 of the exact one */
+    int32_t analytic_forced;  /* 1: this context's STD launches over more than 64 images take the analytic band although the caller
+                                 did not ask for it (the device failed the check, or LFI_FLAG_STD_BAND_PROBE_FAIL) */
+    int32_t sums;             /* sums checked */
+    float worst_fraction;     /* the largest error seen, as a fraction of the budget */
+    float probe_ms;           /* what the check cost, once per device (host wall clock) */
+    char message[160];
+} lfi_std_band;
+int lfi_std_band_info(lfi_ctx *ctx, lfi_std_band *out);
 /* name of the blend kernel the last lfi_render / lfi_benchmark of this context launched ("" before the first) — lets the
  * measurement harness label its numbers with what actually ran (dispatch depends on shape, weights and mode) */
 const char *lfi_last_kernel_name(const lfi_ctx *ctx);

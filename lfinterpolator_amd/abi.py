@@ -16,6 +16,7 @@ LFI_FLAG_TEN_ROUND_PER_BATCH = 2
 LFI_FLAG_SINGLE_SWEEP_DIRECTION = 4
 LFI_FLAG_STD_ANALYTIC_BAND = 8
 LFI_FLAG_STD_MEASURED_BAND = 16
+LFI_FLAG_STD_BAND_PROBE_FAIL = 32
 LFI_KERNEL_FOCUS_ESTIMATE = 2
 METHODS = {"STD": LFI_METHOD_STD, "TEN_WM": LFI_METHOD_TEN_WM, "FOCUS": LFI_KERNEL_FOCUS_ESTIMATE}
 
@@ -26,7 +27,7 @@ ABI_SYMBOLS = [
     "lfi_attach_views", "lfi_views_device_ptr", "lfi_focus_map", "lfi_render", "lfi_benchmark", "lfi_timer_start",
     "lfi_timer_stop", "lfi_sync", "lfi_download_view", "lfi_download_map", "lfi_download_quilt", "lfi_download_quilt_tiles", "lfi_release_inputs", "lfi_alloc_pinned", "lfi_free_pinned", "lfi_upload_map", "lfi_set_stream",
     "lfi_set_variant", "lfi_list_variants", "lfi_download_coords", "lfi_download_prequant", "lfi_debug_mfma_f16",
-    "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_fill_synthetic_scene", "lfi_upload_image_async", "lfi_upload_wait", "lfi_render_stream", "lfi_compare_view", "lfi_debug_mfma_f16_chain", "lfi_debug_pk_minmax3_f16",
+    "lfi_grid_modified", "lfi_prepare", "lfi_memory_info", "lfi_last_kernel_name", "lfi_fill_synthetic_images", "lfi_set_output_layout", "lfi_view_layout", "lfi_fill_synthetic_scene", "lfi_upload_image_async", "lfi_upload_wait", "lfi_render_stream", "lfi_compare_view", "lfi_debug_mfma_f16_chain", "lfi_debug_pk_minmax3_f16", "lfi_std_band_info",
 ]
 
 
@@ -57,6 +58,11 @@ class ViewLayout(C.Structure):
 
 class Quality(C.Structure):
     _fields_ = [("mse", C.c_double * 3), ("psnr", C.c_double * 3), ("psnr_all", C.c_double), ("ssim", C.c_double * 3), ("ssim_all", C.c_double)]
+
+
+class StdBandInfo(C.Structure):
+    _fields_ = [("probed", C.c_int32), ("within_budget", C.c_int32), ("analytic_forced", C.c_int32), ("sums", C.c_int32),
+                ("worst_fraction", C.c_float), ("probe_ms", C.c_float), ("message", C.c_char * 160)]
 
 
 class MemoryInfo(C.Structure):
@@ -134,6 +140,7 @@ def load_hip_library() -> C.CDLL:
         "lfi_view_layout": (i, [vp, C.POINTER(ViewLayout)]),
         "lfi_fill_synthetic_images": (i, [vp, C.c_uint32, i, i]),
         "lfi_memory_info": (i, [vp, C.POINTER(MemoryInfo)]),
+        "lfi_std_band_info": (i, [vp, C.POINTER(StdBandInfo)]),
         "lfi_last_kernel_name": (C.c_char_p, [vp]),
     }
     for name, (res, args) in sig.items():
@@ -317,6 +324,12 @@ class Context:
         mi = MemoryInfo()
         self._check(self._lib.lfi_memory_info(self._h, C.byref(mi)))
         return mi
+
+    def std_band_info(self) -> StdBandInfo:
+        """The band method's self-check on this device (runs it if it has not run yet)."""
+        info = StdBandInfo()
+        self._check(self._lib.lfi_std_band_info(self._h, C.byref(info)))
+        return info
 
     def last_kernel_name(self) -> str:
         return self._lib.lfi_last_kernel_name(self._h).decode()

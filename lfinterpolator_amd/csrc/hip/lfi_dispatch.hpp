@@ -14,6 +14,7 @@
 #include "blend_stdxa.hpp"
 #include "blend_af.hpp"
 #include "blend_wave.hpp"
+#include "lfi_band_probe.hpp"
 
 namespace {
 
@@ -672,6 +673,19 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
     if(all_focus && a_in.map_index == 1)
         if(int rc = join_filter(c)) // the filtered map may still be in the making on the side stream
             return rc;
+    if(method == LFI_METHOD_STD && a_in.k_pad > 64 && c->weights_scalable && c->weights_sum_ok && !a_in.prequant && !(a_in.flags & LFI_FLAG_STD_ANALYTIC_BAND))
+    {
+        // more than 64 images: the band's measured bound must hold on THIS device (lfi_band_probe.hpp: measured once per device)
+        bool forced = false;
+        if(int rc = std_band_forced_analytic(c, &forced))
+            return rc;
+        if(forced)
+        {
+            KernelArgs a = a_in;
+            a.flags |= LFI_FLAG_STD_ANALYTIC_BAND;
+            return launch_blend(c, method, all_focus, a);
+        }
+    }
     if(c->inputs_released && !(wants_derived_copy(c, method, all_focus, a_in) && ensure_planar(c)))
         return fail(c, LFI_EINVAL, "the RGBA inputs were released (lfi_release_inputs): only fixed-focus renders whose offsets the planar copy was built for "
                                    "are served (no all-focus render, debug mode, weights outside [0, 2) or larger offsets) - upload the images again");

@@ -887,6 +887,30 @@ int lfi_memory_info(lfi_ctx *ctx, lfi_memory *out)
     return LFI_OK;
 }
 
+int lfi_std_band_info(lfi_ctx *ctx, lfi_std_band *out)
+{
+    if(!ctx || !out)
+        return LFI_EINVAL;
+    if(int rc = bind(ctx))
+        return rc;
+    const BandProbe *p = nullptr;
+    if(int rc = run_band_probe(ctx, &p))
+        return rc;
+    std::memset(out, 0, sizeof(*out));
+    out->probed = p->done;
+    out->within_budget = p->ok;
+    out->analytic_forced = (!p->ok || (ctx->flags & LFI_FLAG_STD_BAND_PROBE_FAIL)) && !(ctx->flags & LFI_FLAG_STD_ANALYTIC_BAND);
+    out->sums = p->sums;
+    out->worst_fraction = p->worst;
+    out->probe_ms = p->ms;
+    std::snprintf(out->message, sizeof(out->message),
+                  p->ok ? (ctx->flags & LFI_FLAG_STD_BAND_PROBE_FAIL ? "measured bound holds (worst %.3f of the budget over %d sums); analytic band forced by LFI_FLAG_STD_BAND_PROBE_FAIL"
+                                                                      : "measured bound holds on this device: worst %.3f of the budget over %d sums")
+                        : "measured bound VIOLATED on this device (worst %.3f of the budget over %d sums): STD over more than 64 images takes the analytic band",
+                  p->worst, p->sums);
+    return LFI_OK;
+}
+
 const char *lfi_last_kernel_name(const lfi_ctx *ctx)
 {
     return ctx ? ctx->last_kernel : "";

@@ -910,6 +910,42 @@ def test_mfma_f16_accumulation_error_bound(shape, gpu):
     ctx.close()
 
 
+def test_std_band_self_check_on_the_device(gpu, oracle_c):
+    """The measured bound behind the band of STD on more than 64 images is checked on the device in use (round 5, lfi_std_band_info):
+    the first such launch measures the matrix pipe's accumulation error over adversarial operand sets; the record says the bound holds
+    (worst case below the budget) and what the check cost.  LFI_FLAG_STD_BAND_PROBE_FAIL makes a context behave as if its device had
+    failed: the launches take the analytic band — and still give the oracle's bytes (fixed focus and all-focus, both band kernels)."""
+    cols, rows, W, H, V = 15, 15, 256, 12, 24
+    n = cols * rows
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.1, 0.3, 3.0, 1.783, V)
+    lf = oracle_c.synthetic_lf(n, W, H, 5)
+    lf[..., :3] = (lf[..., :3] // 2) * 2          # many sums on or next to x.5
+    lf[::2, :, :, :3] += 1
+    lf[..., 3] = 255
+    want = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, threads=8)
+    map1 = np.zeros((H, W, 4), np.uint8)
+    map1[..., 0] = (np.arange(W)[None, :] // 16 * 37 + np.arange(H)[:, None] * 5) % 256
+    map1[..., 1] = map1[..., 2] = map1[..., 0]
+    map1[..., 3] = 255
+    want_af = oracle_c.blend_std(lf, hp.focused_offsets, hp.offsets, hp.weights, all_focus=True, map_plane=map1, focus=hp.focus, rng=hp.range, threads=8)
+    for flags, forced in ((0, False), (gpu.LFI_FLAG_STD_BAND_PROBE_FAIL, True), (gpu.LFI_FLAG_STD_BAND_PROBE_FAIL | gpu.LFI_FLAG_STD_ANALYTIC_BAND, False)):
+        ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf, flags=flags)
+        ctx.render("STD")
+        ctx.sync()
+        assert ctx.last_kernel_name() == "blend_stdx<STD>"
+        assert (ctx.download_views() == want).all(), flags
+        ctx.upload_map(1, map1)
+        ctx.render("STD", all_focus=True)
+        ctx.sync()
+        assert (ctx.download_views() == want_af).all(), (flags, "all-focus")
+        info = ctx.std_band_info()
+        assert info.probed == 1 and info.within_budget == 1 and info.sums >= 20000 and 0.0 < info.worst_fraction <= 1.0, info.message
+        assert info.analytic_forced == int(forced), (flags, info.message)
+        assert info.probe_ms < 200.0
+        ctx.close()
+    print(f"band self-check: {info.message.decode()}; cost {info.probe_ms:.2f} ms once per device")
+
+
 def test_std_near_half_integer_sums_from_precise_weights(gpu, oracle_c):
     """End-to-end companion of the accumulation-bound test: sums S that land within 2^-12 of x.5 (inside the rounding band, but
     not exact ties) built from weights with ≥ 10 significant bits.  Zero offsets (focus 0), so output pixel x blends pixel x of
