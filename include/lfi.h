@@ -55,8 +55,10 @@ enum {
      * (src/kernels.cu:326), Tensors::process the unfiltered map 0 (src/kernels.cu:430) — an inconsistency of the reference
      * (SURVEY.md defect D7) that is reproduced so that outputs match it.  With this flag both methods read map 1. */
     LFI_FLAG_UNIFIED_FOCUS_MAP = 1u,
-    /* TEN_WM debug numerics: re-round the accumulator to fp16 after every 16-image batch, which reproduces the
-     * reference's half-accumulator WMMA model (oracle model M16) instead of one final rounding */
+    /* TEN_WM debug numerics: re-round the accumulator to fp16 after every 16-image batch — the reference's half-accumulator WMMA model
+     * (wmma::mma_sync with half fragments, src/kernels.cu:418-447; oracle model M16) instead of one final rounding.  Byte for byte the
+     * oracle's M16 since round 5: the sums of a batch are formed exactly (fp64 on the vector pipe, one pixel per lane) and rounded once.
+     * A debug mode: two orders of magnitude slower than the matrix-core kernels. */
     LFI_FLAG_TEN_ROUND_PER_BATCH = 2u,
     /* Fixed-focus launches over the planar input copy alternate their sweep direction from launch to launch, so that the input rows
      * one launch read last — still in the 256 MB Infinity Cache — are the first the next launch reads (repeated renders of one light

@@ -19,7 +19,8 @@
 // byte→half conversion is a zero-extension (one v_perm_b32 per two values) and is exact; products with fp16 weights are
 // exact in fp32; the MFMA accumulates in fp32; the epilogue scales by 2^24 (exact), rounds ONCE to fp16 (RN-even) and
 // truncates to u8 with saturation like __half2uchar_rz (src/kernels.cu:393).  The reference's accumulator is fp16 and is
-// re-rounded per 16-image batch; LFI_FLAG_TEN_ROUND_PER_BATCH reproduces that model for parity debugging.
+// re-rounded per 16-image batch; LFI_FLAG_TEN_ROUND_PER_BATCH reproduces that model EXACTLY, in double precision on the vector pipe
+// (blend_ten_m16 below), for parity debugging.
 #pragma once
 
 #include "lfi_device.hpp"
@@ -97,7 +98,7 @@ __device__ __forceinline__ void store_run(uint32_t *p, const uint32_t (&v)[PXL])
 
 // One wave = one run of 32*PXL pixels of one image row × 32*MT views per pass.
 // A 256-thread workgroup holds 4 waves: VPW of them share a pixel run and take different view passes.
-template <int PXL, int MT, bool ALLFOCUS, bool PER_BATCH>
+template <int PXL, int MT, bool ALLFOCUS>
 __global__ void __launch_bounds__(256) blend_ten_direct(const KernelArgs a, const int tiles_x, const int n_tiles,
                                                         const int view_passes, const int vpw)
 {
@@ -207,22 +208,6 @@ __global__ void __launch_bounds__(256) blend_ten_direct(const KernelArgs a, cons
                         acc[m][i][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag[m], b, acc[m][i][c], 0, 0, 0);
                 }
             }
-            if constexpr(PER_BATCH)
-            {
-                // reference model M16: the accumulator fragment is fp16 (src/kernels.cu:422), so re-round after each batch
-#pragma unroll
-                for(int m = 0; m < MT; m++)
-#pragma unroll
-                    for(int i = 0; i < PXL; i++)
-#pragma unroll
-                        for(int c = 0; c < 3; c++)
-#pragma unroll
-                            for(int e = 0; e < 16; e++)
-                            {
-                                _Float16 t = static_cast<_Float16>(acc[m][i][c][e] * 16777216.0f);
-                                acc[m][i][c][e] = static_cast<float>(t) * (1.0f / 16777216.0f);
-                            }
-            }
         }
 
         // ---- epilogue: scale, round to fp16 once, truncate, pack RGBA, store PXL pixels per (lane, view) -----------------------
@@ -268,6 +253,114 @@ __global__ void __launch_bounds__(256) blend_ten_direct(const KernelArgs a, cons
                         }
                 }
             }
+    }
+}
+
+// ---- LFI_FLAG_TEN_ROUND_PER_BATCH: the reference's half-accumulator model, EXACTLY (round 5) ------------------------------------------
+// wmma::mma_sync with a half accumulator fragment (src/kernels.cu:418-447) re-rounds the running sum to fp16 after every batch of 16
+// images; the oracle's model M16 is acc ← RN_fp16(acc + Σ_16 w·p) with the inner sum EXACT.  Rounds 1–4 reproduced it on the matrix pipe
+// (an fp32 MFMA accumulation of the 16 products, then a rounding to fp16): the pipe's own fp32 roundings and the second rounding made
+// ≈ 1e-4 of the bytes differ.  A matrix core cannot give the exact sum (its accumulator keeps 24 bits, the products of a batch span up to 43),
+// so the debug mode computes it where it CAN be exact — in double precision on the vector pipe (products of an fp16 weight and a byte and
+// sums of 16 of them, 48 bits at most, are exact in fp64) — and rounds once, to nearest even, with the oracle's own algorithm.  One pixel
+// per lane, 8 views per pass; a debug mode, not a fast one.
+__device__ __forceinline__ uint32_t f64_to_f16_rne(const double x) // finite x (the oracle's lfo_f64_to_f16, oracle/lfi_oracle.c)
+{
+    const uint32_t sign = x < 0.0 ? 0x8000u : 0u;
+    const double a = __builtin_fabs(x);
+    if(a >= 65520.0)
+        return sign | 0x7c00u;
+    if(a < 0x1p-14)                                           // subnormal result (or the smallest normal, by a carry): multiples of 2^-24
+        return sign | uint32_t(__builtin_rint(a * 0x1p24));
+    int e = int((__builtin_bit_cast(uint64_t, a) >> 52) & 0x7ffu) - 1023;
+    double q = __builtin_rint(__builtin_ldexp(a, 10 - e));   // in [1024, 2048], exact scaling, ONE rounding (v_rndne_f64: to even)
+    if(q >= 2048.0)
+    {
+        q = 1024.0;
+        e++;
+    }
+    return sign | (uint32_t(e + 15) << 10) | (uint32_t(q) - 1024u);
+}
+
+template <bool ALLFOCUS>
+__global__ void __launch_bounds__(256) blend_ten_m16(const KernelArgs a)
+{
+    constexpr int VP = 8;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int W = a.width, H = a.height;
+    if(x >= W || y >= H)
+        return;
+    const uint32_t *grid32 = reinterpret_cast<const uint32_t *>(a.grid);
+    const size_t plane_px = (size_t)W * (size_t)H;
+    float focus_px = 0.0f;
+    if constexpr(ALLFOCUS)
+        focus_px = decode_focus(a.maps + (size_t)a.map_index * plane_px * 4, W, H, x, y, a.focus, a.range);
+    for(int vb = a.v0; vb < a.v1; vb += VP)
+    {
+        uint32_t acc[VP][3]; // fp16 bit patterns
+#pragma unroll
+        for(int v = 0; v < VP; v++)
+            acc[v][0] = acc[v][1] = acc[v][2] = 0u;
+        for(int kb = 0; kb < a.k_pad; kb += 16)
+        {
+            double s[VP][3];
+#pragma unroll
+            for(int v = 0; v < VP; v++)
+                s[v][0] = s[v][1] = s[v][2] = 0.0;
+            for(int k = 0; k < 16; k++)
+            {
+                const int g = kb + k, gi = min(g, a.n_images - 1); // padded images carry zero weights; any valid pixel will do
+                int sx, sy;
+                if constexpr(ALLFOCUS)
+                {
+                    const lfi_float2 off = a.offsets[gi];
+                    sx = clampi(warp_float(x, focus_px, off.x), 0, W - 1);
+                    sy = clampi(warp_float(y, focus_px, off.y), 0, H - 1);
+                }
+                else
+                {
+                    const lfi_int2 off = a.focused[gi];
+                    sx = clampi(x + off.x, 0, W - 1);
+                    sy = clampi(y + off.y, 0, H - 1);
+                }
+                const uint32_t px = grid32[(size_t)gi * plane_px + (size_t)sy * W + sx];
+                const double p0 = double(px & 255u), p1 = double((px >> 8) & 255u), p2 = double((px >> 16) & 255u);
+#pragma unroll
+                for(int v = 0; v < VP; v++)
+                {
+                    const double wv = double(__builtin_bit_cast(_Float16, a.w16[(size_t)(vb + v) * a.k_pad + g])); // rows up to v_pad exist, zero-filled
+                    s[v][0] = __builtin_fma(wv, p0, s[v][0]); // exact: the products and their partial sums fit 53 bits
+                    s[v][1] = __builtin_fma(wv, p1, s[v][1]);
+                    s[v][2] = __builtin_fma(wv, p2, s[v][2]);
+                }
+            }
+#pragma unroll
+            for(int v = 0; v < VP; v++)
+#pragma unroll
+                for(int c = 0; c < 3; c++)
+                    acc[v][c] = f64_to_f16_rne(double(__builtin_bit_cast(_Float16, uint16_t(acc[v][c]))) + s[v][c]);
+        }
+#pragma unroll
+        for(int v = 0; v < VP; v++)
+        {
+            const int view = vb + v;
+            if(view >= a.v1)
+                break;
+            uint32_t rgba = 0xff000000u;
+            float pre[3];
+#pragma unroll
+            for(int c = 0; c < 3; c++)
+            {
+                pre[c] = float(__builtin_bit_cast(_Float16, uint16_t(acc[v][c])));
+                rgba |= uint32_t(fminf(fmaxf(pre[c], 0.0f), 255.0f)) << (8 * c); // __half2uchar_rz: truncate, saturate
+            }
+            reinterpret_cast<uint32_t *>(a.views)[(size_t)view * plane_px + (size_t)y * W + x] = rgba;
+            if(a.prequant != nullptr && view == a.prequant_view)
+            {
+                float *pq = a.prequant + ((size_t)y * W + x) * 3;
+                pq[0] = pre[0], pq[1] = pre[1], pq[2] = pre[2];
+            }
+        }
     }
 }
 

@@ -40,22 +40,21 @@ void launch_ten_direct(const lfi_ctx *c, const KernelArgs &a, bool all_focus)
     const int tiles_per_wg = 4 / vpw;
     const dim3 grid((n_tiles + tiles_per_wg - 1) / tiles_per_wg), block(256);
     hipStream_t st = stream_of(c);
-    note_kernel(c, "blend_ten_direct");
-    if constexpr(PXL == 1 && MT == 2)
+    if(flags_of(c) & LFI_FLAG_TEN_ROUND_PER_BATCH)
     {
-        if(flags_of(c) & LFI_FLAG_TEN_ROUND_PER_BATCH)
-        {
-            if(all_focus)
-                hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, true, true>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
-            else
-                hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false, true>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
-            return;
-        }
+        // the reference's half-accumulator model (oracle M16), exact: fp64 on the vector pipe, one pixel per lane (blend_ten.hpp)
+        note_kernel(c, "blend_ten_m16");
+        if(all_focus)
+            hipLaunchKernelGGL(lfi::blend_ten_m16<true>, pixel_grid_of(c), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(lfi::blend_ten_m16<false>, pixel_grid_of(c), dim3(256), 0, st, a);
+        return;
     }
+    note_kernel(c, "blend_ten_direct");
     if(all_focus)
-        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, true, false>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
+        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, true>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
     else
-        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false, false>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
+        hipLaunchKernelGGL((lfi::blend_ten_direct<PXL, MT, false>), grid, block, 0, st, a, tiles_x, n_tiles, passes, vpw);
 }
 
 template <bool STD, int MT, bool NT_STORE, int KC = 64, int WGS = 2>
