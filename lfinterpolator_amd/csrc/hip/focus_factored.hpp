@@ -688,20 +688,17 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
                         e[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_extra, int(src + uint32_t(rows * (2 * i + par)) * row_b), 0);
             }
         };
-        // A lane's four slots are 32 contiguous bytes, stored by two ds_write_b128; the 8 lanes a 16-byte store serves together would hit
-        // every bank twice if all of them stored their lower half first (lanes l and l + 4 are 128 bytes apart: 23 % of all LDS cycles were
-        // conflicts) — so lanes with bit 2 set store their UPPER half first: the halves of 8 neighbouring lanes then tile all 32 banks.
-        const bool upper_first = (lane & 4) != 0;
-        const int first_off = upper_first ? 16 : 0;
+        // (A lane's four slots are 32 contiguous bytes, stored by two ds_write_b128: the 8 lanes a 16-byte store serves together hit every
+        // bank twice — 23 % of all LDS cycles are conflicts.  Letting the lanes with bit 2 set store their upper half first removes them, at four
+        // selects per lane-load: slower, 1.54 → 1.60 ms — the kernel is bound by vector-instruction issue, not by the LDS; profiles/r05_notes.md.)
         auto put = [&](uint8_t *const dst, const u32x4 px) { // four padded pixels [R,G,B,B'] → four slots [R,G | B,B'] of u16
-            const uint32_t p0 = upper_first ? px.z : px.x, p1 = upper_first ? px.w : px.y, p2 = upper_first ? px.x : px.z, p3 = upper_first ? px.y : px.w;
             u32x4 s0, s1;
-            s0.x = __builtin_amdgcn_perm(0u, p0, 0x0c010c00u), s0.y = __builtin_amdgcn_perm(0u, p0, 0x0c030c02u);
-            s0.z = __builtin_amdgcn_perm(0u, p1, 0x0c010c00u), s0.w = __builtin_amdgcn_perm(0u, p1, 0x0c030c02u);
-            s1.x = __builtin_amdgcn_perm(0u, p2, 0x0c010c00u), s1.y = __builtin_amdgcn_perm(0u, p2, 0x0c030c02u);
-            s1.z = __builtin_amdgcn_perm(0u, p3, 0x0c010c00u), s1.w = __builtin_amdgcn_perm(0u, p3, 0x0c030c02u);
-            *reinterpret_cast<u32x4 *>(dst + first_off) = s0;
-            *reinterpret_cast<u32x4 *>(dst + (16 - first_off)) = s1;
+            s0.x = __builtin_amdgcn_perm(0u, px.x, 0x0c010c00u), s0.y = __builtin_amdgcn_perm(0u, px.x, 0x0c030c02u);
+            s0.z = __builtin_amdgcn_perm(0u, px.y, 0x0c010c00u), s0.w = __builtin_amdgcn_perm(0u, px.y, 0x0c030c02u);
+            s1.x = __builtin_amdgcn_perm(0u, px.z, 0x0c010c00u), s1.y = __builtin_amdgcn_perm(0u, px.z, 0x0c030c02u);
+            s1.z = __builtin_amdgcn_perm(0u, px.w, 0x0c010c00u), s1.w = __builtin_amdgcn_perm(0u, px.w, 0x0c030c02u);
+            *reinterpret_cast<u32x4 *>(dst) = s0;
+            *reinterpret_cast<u32x4 *>(dst + 16) = s1;
         };
         auto store = [&](const u32x4 (&m)[MAIN_N], const u32x4 (&e)[EXTRA_N], const Geo &g) {
             // (every wave has passed the previous barrier: the reducing waves are done with this half, which held the step before the one they reduce now)
@@ -863,9 +860,8 @@ __device__ __forceinline__ uint64_t readlane64(const uint64_t v, const int lane)
 
 // E'(slot, ty)(qx) for the flagged rows: like focus_range, but the source row of view k is the one the reference's
 // arithmetic gives for (row y, view k) plus (ty − 1)·ry.  Persistent.  XCD x (blocks b ≡ x mod 8) takes the 256-column tiles
-// ≡ x mod 8; its waves stride over (row, tile, candidate) — neighbouring rows and candidates read almost the same
-// source lines, which therefore meet in one L2.  The three ty lines are computed
-// together.  Per-view parameters live in lane k's registers (no scalar loads in the view loop); the samples of view k + 1
+// ≡ x mod 8; its waves stride over the flagged (row, candidate) entries × those tiles — neighbouring rows read almost the same
+// source lines, which therefore meet in one L2.  Per-view parameters live in lane k's registers (no scalar loads in the view loop); the samples of view k + 1
 // are in flight while view k is reduced.
 __device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const FocusWork &w, const uint32_t block, const uint32_t blocks)
 {
@@ -880,15 +876,18 @@ __device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const Focu
     const float offy_l = a.offsets[a.focus_ids[kk]].y;
     const uint8_t *pad = reinterpret_cast<const uint8_t *>(w.pad) + 16u * lane;
     const size_t tap_stride = (size_t)a.radius_y * w.Wp * 4;
-    for(uint32_t u = wave_id; u < uint32_t(a.height) * my_tiles * FOCUS_STEPS; u += n_waves)
+    // units = the flagged (row, candidate) entries of the row lists (candidate-major, rows ascending: focus_plan_lists / focus_plan_prefix) × this
+    // XCD's tiles.  (Rounds 3–4 walked ALL (row, tile, candidate) triples and skipped the unflagged ones after one load each: 270 dependent
+    // L2 round trips per wave — the pass's whole time once it ran at one wave per SIMD beside the persistent range kernel.)
+    const focus_const_u32_ptr row_prefix = (focus_const_u32_ptr)(uintptr_t)w.prefix;
+    const uint32_t entries = row_prefix[32];
+    int i = 0;
+    for(uint32_t u = wave_id; u < entries * my_tiles; u += n_waves)
     {
-        // (row, tile of this XCD, candidate), candidate fastest: most units are unflagged and cost one uniform load
-        const int i = int(u % FOCUS_STEPS);
-        const uint32_t tile = xcd + 8u * ((u / FOCUS_STEPS) % my_tiles);
-        const int y = int(u / (FOCUS_STEPS * my_tiles));
+        const uint32_t e = u / my_tiles, tile = xcd + 8u * (u % my_tiles);
+        prefix_walk(row_prefix, e, i); // (u only grows: the walk continues where the last unit's ended)
+        const int y = __builtin_amdgcn_readfirstlane(int(w.rows[(size_t)i * a.height + (e - row_prefix[i])]));
         const uint32_t flags = __builtin_amdgcn_readfirstlane(w.bady[y]);
-        if(((flags >> i) & 1u) == 0u)
-            continue;
         {
             const uint32_t slot = line_slot(__builtin_amdgcn_readfirstlane(w.rowbase[y]), flags, i);
             if(slot >= uint32_t(w.R_cap))
@@ -903,52 +902,43 @@ __device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const Focu
 #pragma unroll
             for(int t = 0; t < 3; t++)
                 tm |= ((__builtin_amdgcn_readfirstlane(w.tapy[(size_t)t * a.height + y]) >> i) & 1u) << t;
-            RangeAcc4 acc[3];
-#pragma unroll
-            for(int t = 0; t < 3; t++)
-                acc[t].init();
-            u32x4 cur[3], nxt[3];
-            auto fetch = [&](const int k, u32x4 (&v)[3]) {
-                const uint8_t *p = pad + readlane64(off_l, k);
-#pragma unroll
-                for(int t = 0; t < 3; t++)
-                    if(tm & (1u << t)) // wave-uniform
-                        v[t] = *reinterpret_cast<const u32x4_a4 *>(p + t * tap_stride);
-                    else
-                        v[t] = u32x4{0u, 0u, 0u, 0u};
-            };
-            // two views per reduction (min3 / max3); past the last view the index clamps to it (reducing a view twice changes nothing)
-            auto reduce2 = [&](const u32x4 (&va)[3], const u32x4 (&vb)[3]) {
-#pragma unroll
-                for(int t = 0; t < 3; t++)
-                    if(tm & (1u << t))
-                        acc[t].add2(va[t], vb[t]);
-            };
+            // One tap at a time (almost always there is just one: t = 2), EIGHT views in flight: these passes are latency-bound, and since
+            // round 5 they run at one wave per SIMD beside the persistent range kernel (focus_range_t) — their memory-level parallelism per
+            // wave is what sets their time (three taps' registers for a two-pair prefetch took 0.73 ms beside it).
             const int last = n_ids - 1;
-            u32x4 cur2[3], nxt2[3];
-            fetch(0, cur);
-            fetch(min(1, last), nxt);
-            int k = 0;
-            for(; k + 4 < n_ids; k += 4) // two pairs per trip: the buffers swap roles without register moves
-            {
-                fetch(k + 2, cur2);
-                fetch(k + 3, nxt2);
-                reduce2(cur, nxt);
-                fetch(k + 4, cur);
-                fetch(min(k + 5, last), nxt);
-                reduce2(cur2, nxt2);
-            }
-            fetch(min(k + 2, last), cur2); // tail: views k, k + 1 are loaded; k + 2, k + 3 clamp to the last view
-            fetch(min(k + 3, last), nxt2);
-            reduce2(cur, nxt);
-            reduce2(cur2, nxt2);
-#pragma unroll
+#pragma unroll 1
             for(int t = 0; t < 3; t++)
-                if(tm & (1u << t)) // the other lines of the slot stay unwritten: focus_line_keys takes those taps from E
+            {
+                if(!(tm & (1u << t))) // wave-uniform
+                    continue;
+                RangeAcc4 acc;
+                acc.init();
+                u32x4 va[4], vb[4];
+                auto fetch4 = [&](const int k0, u32x4 (&v)[4]) { // views k0 … k0 + 3, clamped to the last (reducing a view twice changes nothing)
+#pragma unroll
+                    for(int q = 0; q < 4; q++)
+                        v[q] = *reinterpret_cast<const u32x4_a4 *>(pad + readlane64(off_l, min(k0 + q, last)) + t * tap_stride);
+                };
+                fetch4(0, va);
+                fetch4(4, vb);
+                for(int k = 0; k < n_ids; k += 8)
                 {
-                    uint16_t *dst = w.Er + ((size_t)slot * 3 + t) * w.We_p + tile * 256 + 4 * lane;
-                    *reinterpret_cast<u32x2 *>(dst) = acc[t].encode();
+                    acc.add2(va[0], va[1]);
+                    acc.add2(va[2], va[3]);
+                    if(k + 8 < n_ids)
+                        fetch4(k + 8, va);
+                    if(k + 4 < n_ids)
+                    {
+                        acc.add2(vb[0], vb[1]);
+                        acc.add2(vb[2], vb[3]);
+                    }
+                    if(k + 12 < n_ids)
+                        fetch4(k + 12, vb);
                 }
+                // (the other lines of the slot stay unwritten: focus_line_keys takes those taps from E)
+                uint16_t *dst = w.Er + ((size_t)slot * 3 + t) * w.We_p + tile * 256 + 4 * lane;
+                *reinterpret_cast<u32x2 *>(dst) = acc.encode();
+            }
         }
     }
 }
@@ -957,8 +947,10 @@ __device__ __forceinline__ void focus_lines_rows(const KernelArgs &a, const Focu
 // arithmetic for (column x, view k) plus (tx − 1)·rx), a wave takes (64 flagged columns of a candidate, 2 extended rows) units;
 // the source rows are uniform shifts.  XCD x takes the x-th eighth of the row blocks and walks it with all candidates'
 // chunks of a row block back to back (their bands overlap: one L2 serves them).  Same register-resident parameters and
-// one-view-ahead fetch as focus_lines_rows.
-constexpr int FOCUS_COL_ROWS = 2;
+// one-view-ahead fetch as focus_lines_rows.  Round 5: EIGHT rows per unit and one tap at a time (usually there is one): 32 loads in flight per
+// lane instead of 12, a quarter of the units (each starts with a chain of dependent list look-ups) — the pass is latency-bound and runs at one
+// wave per SIMD beside the persistent range kernel.
+constexpr int FOCUS_COL_ROWS = 4;
 __device__ __forceinline__ void focus_lines_cols(const KernelArgs &a, const FocusWork &w, const uint32_t block, const uint32_t blocks)
 {
     constexpr int R = FOCUS_COL_ROWS;
@@ -968,7 +960,7 @@ __device__ __forceinline__ void focus_lines_cols(const KernelArgs &a, const Focu
     const uint32_t n_waves = (blocks >> 3) * 4; // blocks is a multiple of 8
     const focus_const_u32_ptr chunk_prefix = (focus_const_u32_ptr)(uintptr_t)(w.prefix + 66);
     const focus_const_int_ptr ncols = (focus_const_int_ptr)(uintptr_t)w.ncols;
-    const uint32_t row_blocks = uint32_t(w.He_p) / uint32_t(R);
+    const uint32_t row_blocks = (uint32_t(w.He_p) + uint32_t(R) - 1u) / uint32_t(R); // (the last block may reach below the extended image: its rows are not stored)
     const uint32_t rb0 = row_blocks * xcd / 8u, rb1 = row_blocks * (xcd + 1u) / 8u;
     const uint32_t chunks = chunk_prefix[32];
     const int n_ids = a.n_focus_ids;
@@ -993,12 +985,6 @@ __device__ __forceinline__ void focus_lines_cols(const KernelArgs &a, const Focu
         // lane k: byte offset of view k's source row for the block's first extended row
         const int sy_l = w.shifts[4 * (i * FOCUS_MAX_IDS + kk) + 1];
         const uint64_t off_l = ((uint64_t)kk * w.Hp + uint64_t(int(rb) * R - a.radius_y + sy_l + w.Py)) * row_bytes;
-        RangeAcc1 acc[R][3]; // [row of the block][tx]
-#pragma unroll
-        for(int r = 0; r < R; r++)
-#pragma unroll
-            for(int t = 0; t < 3; t++)
-                acc[r][t].init();
         // the taps (tx = t − 1) of this lane's column that need their own line for this candidate (per lane; usually just t = 2): the
         // other loads are masked off — an inactive lane makes no request — and their lines stay unwritten (focus_line_keys reads E there)
         uint32_t tm = 0u;
@@ -1006,57 +992,58 @@ __device__ __forceinline__ void focus_lines_cols(const KernelArgs &a, const Focu
         for(int t = 0; t < 3; t++)
             tm |= ((w.tapx[(size_t)t * a.width + x] >> i) & 1u) << t;
         tm = active ? tm : 0u;
-        uint32_t cur[R][3], nxt[R][3];
-        auto fetch = [&](const int k, uint32_t (&v)[R][3]) {
-            const float offx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(uint32_t, offx_l), k));
-            const uint32_t left = uint32_t(warp_float(x, f, offx) - rx + w.Px) * 4u; // tx = 0 sample column, bytes
-            const uint8_t *row = pad + readlane64(off_l, k);
+        const int last = n_ids - 1;
+#pragma unroll 1
+        for(int t = 0; t < 3; t++)
+        {
+            const bool want = (tm >> t) & 1u;
+            if(__builtin_amdgcn_ballot_w64(want) == 0ull)
+                continue;
+            RangeAcc1 acc[R]; // [row of the block]
 #pragma unroll
-            for(int t = 0; t < 3; t++)
-            {
-                const bool want = (tm >> t) & 1u;
+            for(int r = 0; r < R; r++)
+                acc[r].init();
+            uint32_t cur[R], nxt[R], cur2[R], nxt2[R];
+            auto fetch = [&](const int k, uint32_t (&v)[R]) {
+                const float offx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(uint32_t, offx_l), k));
+                const uint32_t left = uint32_t(warp_float(x, f, offx) - rx + w.Px + t * rx) * 4u; // this tap's sample column, bytes
+                const uint8_t *row = pad + readlane64(off_l, k);
 #pragma unroll
                 for(int r = 0; r < R; r++)
-                    v[r][t] = want ? *reinterpret_cast<const uint32_t *>(row + r * row_bytes + uint32_t(t * rx) * 4u + left) : 0u;
+                    v[r] = want ? *reinterpret_cast<const uint32_t *>(row + r * row_bytes + left) : 0u;
+            };
+            auto reduce2 = [&](const uint32_t (&va)[R], const uint32_t (&vb)[R]) { // two views per reduction (min3 / max3)
+#pragma unroll
+                for(int r = 0; r < R; r++)
+                    acc[r].add2(va[r], vb[r]);
+            };
+            fetch(0, cur);
+            fetch(min(1, last), nxt);
+            int k = 0;
+            for(; k + 4 < n_ids; k += 4)
+            {
+                fetch(k + 2, cur2);
+                fetch(k + 3, nxt2);
+                reduce2(cur, nxt);
+                fetch(k + 4, cur);
+                fetch(min(k + 5, last), nxt);
+                reduce2(cur2, nxt2);
             }
-        };
-        auto reduce2 = [&](const uint32_t (&va)[R][3], const uint32_t (&vb)[R][3]) { // two views per reduction (min3 / max3)
-#pragma unroll
-            for(int r = 0; r < R; r++)
-#pragma unroll
-                for(int t = 0; t < 3; t++)
-                    acc[r][t].add2(va[r][t], vb[r][t]);
-        };
-        const int last = n_ids - 1;
-        uint32_t cur2[R][3], nxt2[R][3];
-        fetch(0, cur);
-        fetch(min(1, last), nxt);
-        int k = 0;
-        for(; k + 4 < n_ids; k += 4)
-        {
-            fetch(k + 2, cur2);
-            fetch(k + 3, nxt2);
+            fetch(min(k + 2, last), cur2);
+            fetch(min(k + 3, last), nxt2);
             reduce2(cur, nxt);
-            fetch(k + 4, cur);
-            fetch(min(k + 5, last), nxt);
             reduce2(cur2, nxt2);
-        }
-        fetch(min(k + 2, last), cur2);
-        fetch(min(k + 3, last), nxt2);
-        reduce2(cur, nxt);
-        reduce2(cur2, nxt2);
-        if(active)
-        {
+            if(want)
+            {
 #pragma unroll
-            for(int r = 0; r < R; r++)
-#pragma unroll
-                for(int t = 0; t < 3; t++)
-                    if((tm >> t) & 1u)
+                for(int r = 0; r < R; r++)
+                    if(int(rb) * R + r < w.He_p)
                     {
                         uint32_t range, tiny;
-                        acc[r][t].result(range, tiny);
+                        acc[r].result(range, tiny);
                         w.Ec[((size_t)t * w.He_p + rb * R + r) * w.C_cap + cs] = static_cast<uint16_t>((range << 4) + tiny);
                     }
+            }
         }
     }
 }
@@ -1370,6 +1357,8 @@ __global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const Focu
     const int rx = a.radius_x, ry = a.radius_y;
     // lanes past the right edge compute pixel 0 and store nothing; the second pixel of a lane at x = W − 1 (odd W) reads
     // one element past a row of badx / E / K, inside the workspace, and is not stored either
+    // (round 5: FOUR pixels per lane — two dwords per sample load, half the wave-loads — measured slower, 436 against 272 µs at 4K: 8-byte
+    // loads at 4-byte alignment and half the waves; profiles/r05_notes.md)
     const int xs = x < W ? x : 0;
     const uint32_t flagged_y = __builtin_amdgcn_readfirstlane(w.bady[y]);
     uint32_t flagged[PPL];
