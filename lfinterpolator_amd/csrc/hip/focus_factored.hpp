@@ -777,50 +777,65 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
         asm volatile("" ::: "memory");
         // The reduction.  LDS reads by inline assembly: every slot is read whole (ds_read_b64) although of the second row of a pair only
         // [R,G] is used — the compiler narrows such a read to ds_read_b32, and 4-byte reads at an 8-byte lane stride run into two-way bank
-        // conflicts (25 % of all LDS cycles, profiles/r05_pmc_range_t_first.txt).  The reads of candidate c + 1 are issued before candidate
-        // c is reduced; LDS returns in order, so lgkmcnt(8) = "the older eight reads have landed" (a scalar load still in flight — the next
-        // step's plan words — only makes the wait longer: it shares the counter).
+        // conflicts (25 % of all LDS cycles, profiles/r05_pmc_range_t_first.txt).  Unit of the pipeline = one ROW PAIR of one candidate: four
+        // reads (two slots × two views), six reductions; the reads of unit u + 1 are issued before unit u is reduced — two sets of 8 registers,
+        // where whole candidates in flight would take two sets of 16 and push the kernel over its register budget.  LDS returns in order,
+        // so lgkmcnt(4) = "the older four reads have landed" (a scalar load still in flight — the next step's plan words — only makes the
+        // wait longer: it shares the counter).
         auto slot_addr = [&](const int c, const int v) {
             return rd_addr + (((dc[v][c >> 1] >> (16 * (c & 1))) & 0xffffu) + half + uint32_t(v) * FRT_VIEW_B);
         };
-        auto read8 = [&](const int c, u32x2 (&sa)[4], u32x2 (&sb)[4]) {
-            const uint32_t pa = slot_addr(c, 0), pb = slot_addr(c, 1);
-#pragma unroll
-            for(int r = 0; r < 4; r++)
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(sa[r]) : "v"(pa), "n"(r * FRT_PW * 8));
-#pragma unroll
-            for(int r = 0; r < 4; r++)
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(sb[r]) : "v"(pb), "n"(r * FRT_PW * 8));
-        };
-        auto reduce = [&](const int c, u32x2 (&sa)[4], u32x2 (&sb)[4], const bool more_in_flight) {
-            if(more_in_flight)
-                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]));
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]));
-            const uint32_t va[6] = {sa[0].x, sa[1].x, sa[2].x, sa[3].x, sa[0].y, sa[2].y}, vb[6] = {sb[0].x, sb[1].x, sb[2].x, sb[3].x, sb[0].y, sb[2].y};
-#pragma unroll
-            for(int r = 0; r < 6; r++)
+        auto read4 = [&](const uint32_t pa, const uint32_t pb, const int pair, u32x2 (&q)[4]) {
+            if(pair == 0)
             {
-                lo[c][r] = min3_bytes(lo[c][r], as_u16x2(va[r]), as_u16x2(vb[r]));
-                hi[c][r] = max3_bytes(hi[c][r], as_u16x2(va[r]), as_u16x2(vb[r]));
+                asm volatile("ds_read_b64 %0, %1" : "=v"(q[0]) : "v"(pa));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[1]) : "v"(pa), "n"(FRT_PW * 8));
+                asm volatile("ds_read_b64 %0, %1" : "=v"(q[2]) : "v"(pb));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[3]) : "v"(pb), "n"(FRT_PW * 8));
             }
+            else
+            {
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[0]) : "v"(pa), "n"(2 * FRT_PW * 8));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[1]) : "v"(pa), "n"(3 * FRT_PW * 8));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[2]) : "v"(pb), "n"(2 * FRT_PW * 8));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[3]) : "v"(pb), "n"(3 * FRT_PW * 8));
+            }
+        };
+        auto reduce = [&](const int c, const int pair, u32x2 (&q)[4], const bool more_in_flight) {
+            if(more_in_flight)
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+            // accumulators of the pair: [R,G] of its two rows, [B,B']
+            const int r0 = 2 * pair, r1 = 2 * pair + 1, rb = 4 + pair;
+            lo[c][r0] = min3_bytes(lo[c][r0], as_u16x2(q[0].x), as_u16x2(q[2].x));
+            hi[c][r0] = max3_bytes(hi[c][r0], as_u16x2(q[0].x), as_u16x2(q[2].x));
+            lo[c][r1] = min3_bytes(lo[c][r1], as_u16x2(q[1].x), as_u16x2(q[3].x));
+            hi[c][r1] = max3_bytes(hi[c][r1], as_u16x2(q[1].x), as_u16x2(q[3].x));
+            lo[c][rb] = min3_bytes(lo[c][rb], as_u16x2(q[0].y), as_u16x2(q[2].y));
+            hi[c][rb] = max3_bytes(hi[c][rb], as_u16x2(q[0].y), as_u16x2(q[2].y));
+            // (pins this unit's reduction in front of the reads after the next: left to the scheduler it sinks below them and the reads
+            // take more registers)
+            asm volatile("" : "+v"(lo[c][r0]), "+v"(lo[c][r1]), "+v"(lo[c][rb]), "+v"(hi[c][r0]), "+v"(hi[c][r1]), "+v"(hi[c][rb]));
         };
 #if defined(FRT_ABL) && (FRT_ABL & 2) // measurement builds: no reduction (barriers only)
         half ^= 2u * FRT_VIEW_B;
         continue;
 #endif
-        // (one set of read registers: the next candidate's reads are issued once this one's are consumed — the other waves of the SIMD cover
-        // the LDS latency; a second set would not fit the register budget above)
-        u32x2 qa[4], qb[4];
+        u32x2 q[2][4];
+        uint32_t pa = slot_addr(0, 0), pb = slot_addr(0, 1);
+        read4(pa, pb, 0, q[0]);
 #pragma unroll
-        for(int c = 0; c < CPW; c++)
+        for(int u = 0; u < 2 * CPW; u++)
         {
-            read8(c, qa, qb);
-            reduce(c, qa, qb, false);
-            // (pins this candidate's reduction in front of the next candidate's reads: left to the scheduler the reduction sinks below them
-            // and the reads take a second set of 16 registers)
-            asm volatile("" : "+v"(lo[c][0]), "+v"(lo[c][1]), "+v"(lo[c][2]), "+v"(lo[c][3]), "+v"(lo[c][4]), "+v"(lo[c][5]), "+v"(hi[c][0]), "+v"(hi[c][1]),
-                         "+v"(hi[c][2]), "+v"(hi[c][3]), "+v"(hi[c][4]), "+v"(hi[c][5]));
+            const int c = u >> 1, pair = u & 1;
+            if(u + 1 < 2 * CPW)
+            {
+                if(pair == 1) // the next unit starts the next candidate
+                    pa = slot_addr(c + 1, 0), pb = slot_addr(c + 1, 1);
+                read4(pa, pb, pair ^ 1, q[(u + 1) & 1]);
+            }
+            reduce(c, pair, q[u & 1], u + 1 < 2 * CPW);
         }
         half ^= 2u * FRT_VIEW_B;
     }
