@@ -1372,8 +1372,9 @@ __global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const Focu
     const int rx = a.radius_x, ry = a.radius_y;
     // lanes past the right edge compute pixel 0 and store nothing; the second pixel of a lane at x = W − 1 (odd W) reads
     // one element past a row of badx / E / K, inside the workspace, and is not stored either
-    // (round 5: FOUR pixels per lane — two dwords per sample load, half the wave-loads — measured slower, 436 against 272 µs at 4K: 8-byte
-    // loads at 4-byte alignment and half the waves; profiles/r05_notes.md)
+    // (round 5, both measured slower than these 4-byte loads' 272 µs at 4K and removed — profiles/r05_notes.md §2: FOUR pixels per lane, two
+    // dwords per sample load: 436 µs (8-byte loads at 4-byte alignment, half the waves); E staged through LDS by aligned 16-byte LDS-DMA
+    // pieces, five wave-loads per batch of four candidates instead of 36: 469 µs (a barrier and an exposed fetch latency per batch))
     const int xs = x < W ? x : 0;
     const uint32_t flagged_y = __builtin_amdgcn_readfirstlane(w.bady[y]);
     uint32_t flagged[PPL];
