@@ -566,13 +566,11 @@ __global__ void __launch_bounds__(32) focus_plan_patches(const KernelArgs a, con
     plans[group * FOCUS_MAX_IDS + k] = p;
 }
 
-// One workgroup per CU (the patches of two steps fill the LDS): EIGHT REDUCING waves and FOUR LOADING waves.  The texture path takes 16
-// cycles per typed wave-load; issued by the reducing waves themselves — in a burst in front of the barrier, or between the candidates — the
-// loads held every wave while nothing was reduced (the three phases added up: profiles/r05_notes.md).  So the roles are split: the loading
-// waves fetch step s + 1's patches and store its slots into the other half of the LDS while the reducing waves work on step s; ONE barrier
-// per step.  Loading wave L: view L & 1 of the step's pair, rows ≡ L >> 1 (mod 2) of its "main" part (column lane, 64 columns: a patch is at
-// least that wide) and row pairs ≡ L >> 1 (mod 2) of its "extra" part (columns 64 + (lane & 31), row 2·pair + (lane >> 5): all 32 columns
-// whatever the patch's width — columns beyond it land in slots nobody reads).
+// One workgroup per CU (the patches of two steps fill the LDS): EIGHT REDUCING waves and FOUR LOADING waves.  Issued by the reducing waves
+// themselves — in a burst in front of the barrier, or between the candidates — the loads held every wave while nothing was reduced (the
+// three phases added up: profiles/r05_notes.md).  So the roles are split: the loading waves fetch step s + 1's patches, widen them and store
+// its slots into the other half of the LDS while the reducing waves work on step s; ONE barrier per step.  Loading wave L: view L & 1 of the
+// step's pair, the row blocks ≡ L >> 1 (mod 2) of its patch (details at the loading branch below).
 constexpr int FRT_LW = 4; // loading waves
 // At most 136 registers per lane (tests/test_abi_library.py checks the code object): three waves per SIMD then leave room for ONE wave of
 // focus_flagged (100 registers, no LDS) on every SIMD — the flagged passes run BESIDE this kernel on the side stream, as they ran beside focus_range; with
