@@ -100,43 +100,53 @@ __global__ void __launch_bounds__(1024) focus_plan_shifts(const KernelArgs a, co
     w.deltas[i * FOCUS_MAX_IDS + k] = (((int64_t)k * w.Hp + dst[1]) * w.Wp + dst[0]) * 4;
 }
 
-// pad[k][yy][xx] = I_ids[k][clamp(yy − Py)][clamp(xx − Px)]; grid (ceil(Wp/256), Hp, n_ids), a lane writes 4 pixels
+// pad[k][yy][xx] = I_ids[k][clamp(yy − Py)][clamp(xx − Px)]; grid (ceil(Wp/256), ceil(Hp/FOCUS_PAD_ROWS), n_ids), a lane writes 4 pixels of
+// FOCUS_PAD_ROWS consecutive padded rows (it needs every row's successor for the alpha byte: walking down, each source row is read once)
 // k0: the first sampled image of the range this launch pads (gridDim.z of them: all, or the ones that changed)
+constexpr int FOCUS_PAD_ROWS = 8;
 __global__ void __launch_bounds__(64) focus_pad(const KernelArgs a, const FocusWork w, const int k0)
 {
     const int xx = (blockIdx.x * 64 + threadIdx.x) * 4;
     if(xx >= w.Wp)
         return;
-    const int yy = blockIdx.y, k = k0 + blockIdx.z;
+    const int yy0 = blockIdx.y * FOCUS_PAD_ROWS, k = k0 + blockIdx.z;
     const int W = a.width, H = a.height;
     const uint32_t *plane = reinterpret_cast<const uint32_t *>(a.grid) + (size_t)a.focus_ids[k] * ((size_t)W * H);
-    const uint32_t *row = plane + (size_t)clampi(yy - w.Py, 0, H - 1) * W;
-    const uint32_t *below = plane + (size_t)clampi(yy + 1 - w.Py, 0, H - 1) * W; // the padded row yy + 1
     const int x = xx - w.Px;
-    u32x4 v, b;
-    if(x >= 0 && x + 3 <= W - 1)
+    const bool inside = x >= 0 && x + 3 <= W - 1;
+    auto load_row = [&](const int yy) { // the four source pixels of padded row yy (clamp-to-edge both ways)
+        const uint32_t *row = plane + (size_t)clampi(yy - w.Py, 0, H - 1) * W;
+        u32x4 v;
+        if(inside)
+            v = *reinterpret_cast<const u32x4_a4 *>(row + x);
+        else
+        {
+            v.x = row[clampi(x, 0, W - 1)];
+            v.y = row[clampi(x + 1, 0, W - 1)];
+            v.z = row[clampi(x + 2, 0, W - 1)];
+            v.w = row[clampi(x + 3, 0, W - 1)];
+        }
+        return v;
+    };
+    u32x4 v = load_row(yy0);
+#pragma unroll
+    for(int r = 0; r < FOCUS_PAD_ROWS; r++)
     {
-        v = *reinterpret_cast<const u32x4_a4 *>(row + x);
-        b = *reinterpret_cast<const u32x4_a4 *>(below + x);
+        const int yy = yy0 + r;
+        if(yy >= w.Hp) // block-uniform
+            break;
+        const u32x4 b = load_row(yy + 1); // the padded row below
+        // The alpha byte of a padded pixel carries the BLUE of the pixel one padded row below (no pass reads alpha: the reference's
+        // ElementRange looks at R, G, B only, src/kernels.cu:173-194): a padded pixel then widens to focus_range_t's LDS slot
+        // [R, G | B, B'] with two single-source v_perm_b32.
+        u32x4 o;
+        o.x = __builtin_amdgcn_perm(b.x, v.x, 0x06020100u);
+        o.y = __builtin_amdgcn_perm(b.y, v.y, 0x06020100u);
+        o.z = __builtin_amdgcn_perm(b.z, v.z, 0x06020100u);
+        o.w = __builtin_amdgcn_perm(b.w, v.w, 0x06020100u);
+        *reinterpret_cast<u32x4 *>(w.pad + ((size_t)k * w.Hp + yy) * w.Wp + xx) = o; // Wp is a multiple of 4
+        v = b;
     }
-    else
-    {
-        v.x = row[clampi(x, 0, W - 1)];
-        v.y = row[clampi(x + 1, 0, W - 1)];
-        v.z = row[clampi(x + 2, 0, W - 1)];
-        v.w = row[clampi(x + 3, 0, W - 1)];
-        b.x = below[clampi(x, 0, W - 1)];
-        b.y = below[clampi(x + 1, 0, W - 1)];
-        b.z = below[clampi(x + 2, 0, W - 1)];
-        b.w = below[clampi(x + 3, 0, W - 1)];
-    }
-    // The alpha byte of a padded pixel carries the BLUE of the pixel one padded row below (no pass reads alpha: the reference's ElementRange
-    // looks at R, G, B only, src/kernels.cu:173-194): focus_range_t's typed load then returns [R, G | B, B'] — its LDS slot — as it is.
-    v.x = __builtin_amdgcn_perm(b.x, v.x, 0x06020100u);
-    v.y = __builtin_amdgcn_perm(b.y, v.y, 0x06020100u);
-    v.z = __builtin_amdgcn_perm(b.z, v.z, 0x06020100u);
-    v.w = __builtin_amdgcn_perm(b.w, v.w, 0x06020100u);
-    *reinterpret_cast<u32x4 *>(w.pad + ((size_t)k * w.Hp + yy) * w.Wp + xx) = v; // Wp is a multiple of 4
 }
 
 // grid (ceil(max(W,H)/256), 32 candidates, 2 axes): is the uniform shift exact for this column / row?

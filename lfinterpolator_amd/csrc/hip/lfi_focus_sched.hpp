@@ -161,12 +161,12 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool di
     {
         for(int k = 0; k < ctx->n_focus_ids; k++)
             if(image_changed_since(ctx, ctx->h_focus_ids[k], ctx->pad_version))
-                hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, 1), dim3(64), 0, st, a, w, k);
+                hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, (w.Hp + lfi::FOCUS_PAD_ROWS - 1) / lfi::FOCUS_PAD_ROWS, 1), dim3(64), 0, st, a, w, k);
         ctx->pad_version = ctx->grid_version;
     }
     else
     {
-        hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, w.Hp, ctx->n_focus_ids), dim3(64), 0, st, a, w, 0);
+        hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, (w.Hp + lfi::FOCUS_PAD_ROWS - 1) / lfi::FOCUS_PAD_ROWS, ctx->n_focus_ids), dim3(64), 0, st, a, w, 0);
         ctx->pad_version = ctx->grid_tracked ? ctx->grid_version : 0;
         ctx->pad_shift[0] = Sx;
         ctx->pad_shift[1] = Sy;
