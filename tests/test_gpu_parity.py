@@ -501,6 +501,34 @@ def test_focus_map_realistic_geometry(radius, gpu, oracle_c):
 
 
 
+@pytest.mark.parametrize("case", [(1, 1, 64, 20, 0.2, 0.3, None), (1, 2, 100, 33, 0.1, 0.2, None), (2, 1, 7, 5, 0.3, 0.5, (1, 1)), (3, 3, 1024, 70, 0.22, 0.17, None),
+                                  (8, 8, 2048, 96, 0.05, 0.04, (20, 10)), (15, 15, 640, 64, 0.22, 0.17, (6, 4)), (6, 6, 513, 40, -0.3, 0.6, None),
+                                  (9, 9, 300, 48, 0.0, 1.0, (11, 5)), (4, 4, 4096, 36, 0.22, 0.17, None), (5, 3, 190, 130, 0.5, 0.01, None)],
+                         ids=lambda c: "x".join(str(v) for v in c[:4]))
+def test_focus_map_edge_shapes_both_range_passes(case, gpu, oracle_c):
+    """Shapes at the edges of focus_range_t's dispatch (round 5): one and two sampled views (a single step, an odd tail), images narrower than
+    a tile and as wide as the stripes' XCD mapping, shifts whose span per candidate group forces groups of four or the fall-back to
+    focus_range (range 1.0), negative focus, radii from 1 to 20 — `factored` (focus_range_t where its preconditions hold) and
+    `factored_direct` (focus_range), twice each (the padded planes kept), maps 0 and 1 against the oracle."""
+    cols, rows, W, H, f, r, rad = case
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", f, r, 3.0, 1.783, 2)
+    if rad:
+        hp.block_radius = np.array(rad, np.int32)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, 11 + cols + W)
+    lf = (lf // 16 * 16).astype(np.uint8)
+    lf[..., 3] = 255
+    want0 = oracle_c.focus_estimate(lf, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, threads=8)
+    want1 = oracle_c.focus_filter(want0, hp.block_radius)
+    ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    for variant in ("factored", "factored_direct"):
+        ctx.set_variant("FOCUS", variant)
+        for _ in range(2):
+            ctx.focus_map()
+            ctx.sync()
+        assert (ctx.download_map(0) == want0).all() and (ctx.download_map(1) == want1).all(), variant
+    ctx.close()
+
+
 def test_focus_map_padded_planes_are_kept_between_calls(gpu, oracle_c):
     """lfi_focus_map keeps the padded copies of the sampled images while the inputs are unchanged (a focus sweep over one light field pads
     once).  Every call must still give the oracle's bytes: the same parameters again (planes reused), a smaller and a larger focus
