@@ -696,17 +696,23 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
                         e[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_extra, int(src + uint32_t(rows * (2 * i + par)) * row_b), 0);
             }
         };
-        // (A lane's four slots are 32 contiguous bytes, stored by two ds_write_b128: the 8 lanes a 16-byte store serves together hit every
-        // bank twice — 23 % of all LDS cycles are conflicts.  Letting the lanes with bit 2 set store their upper half first removes them, at four
-        // selects per lane-load: slower, 1.54 → 1.60 ms — the kernel is bound by vector-instruction issue, not by the LDS; profiles/r05_notes.md.)
+        // A lane's four slots are 32 contiguous bytes, stored by two ds_write_b128.  The 8 lanes a 16-byte store serves together would hit every
+        // bank twice if all of them stored their lower half first (23 % of all LDS cycles were conflicts), so the lanes with bit 2 set store their
+        // UPPER half first.  Which pixels a lane's first store holds is decided inside the v_perm_b32 that widens them anyway (a per-lane selector
+        // over the pair (pixel 0 | pixel 2), (pixel 1 | pixel 3)): no extra instruction.  (Done with selects it cost four v_cndmask per lane-load
+        // and was slower than the conflicts, 1.54 → 1.60 ms.  Without them the conflicts are gone — LDS busy 58 % → 45 % of the run time — and
+        // the kernel is 1 % faster: it is bound by neither unit, profiles/r05_notes.md.)
+        const bool upper_first = (lane & 4) != 0;
+        const uint32_t sel_rg = upper_first ? 0x0c050c04u : 0x0c010c00u, sel_bb = upper_first ? 0x0c070c06u : 0x0c030c02u;
+        const uint32_t first_off = upper_first ? 16u : 0u;
         auto put = [&](uint8_t *const dst, const u32x4 px) { // four padded pixels [R,G,B,B'] → four slots [R,G | B,B'] of u16
             u32x4 s0, s1;
-            s0.x = __builtin_amdgcn_perm(0u, px.x, 0x0c010c00u), s0.y = __builtin_amdgcn_perm(0u, px.x, 0x0c030c02u);
-            s0.z = __builtin_amdgcn_perm(0u, px.y, 0x0c010c00u), s0.w = __builtin_amdgcn_perm(0u, px.y, 0x0c030c02u);
-            s1.x = __builtin_amdgcn_perm(0u, px.z, 0x0c010c00u), s1.y = __builtin_amdgcn_perm(0u, px.z, 0x0c030c02u);
-            s1.z = __builtin_amdgcn_perm(0u, px.w, 0x0c010c00u), s1.w = __builtin_amdgcn_perm(0u, px.w, 0x0c030c02u);
-            *reinterpret_cast<u32x4 *>(dst) = s0;
-            *reinterpret_cast<u32x4 *>(dst + 16) = s1;
+            s0.x = __builtin_amdgcn_perm(px.z, px.x, sel_rg), s0.y = __builtin_amdgcn_perm(px.z, px.x, sel_bb);
+            s0.z = __builtin_amdgcn_perm(px.w, px.y, sel_rg), s0.w = __builtin_amdgcn_perm(px.w, px.y, sel_bb);
+            s1.x = __builtin_amdgcn_perm(px.x, px.z, sel_rg), s1.y = __builtin_amdgcn_perm(px.x, px.z, sel_bb);
+            s1.z = __builtin_amdgcn_perm(px.y, px.w, sel_rg), s1.w = __builtin_amdgcn_perm(px.y, px.w, sel_bb);
+            *reinterpret_cast<u32x4 *>(dst + first_off) = s0;
+            *reinterpret_cast<u32x4 *>(dst + (first_off ^ 16u)) = s1;
         };
         auto store = [&](const u32x4 (&m)[MAIN_N], const u32x4 (&e)[EXTRA_N], const Geo &g) {
             // (every wave has passed the previous barrier: the reducing waves are done with this half, which held the step before the one they reduce now)
@@ -1239,6 +1245,9 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
     constexpr uint32_t CG = 4;
     const uint32_t chunks_w = (uint32_t((W + 63) / 64) + CG - 1) / CG;
     int i = 0;
+#if defined(LK_SKIP) && (LK_SKIP & 1) // measurement builds (tools/line_keys_parts.sh): the kernel without one of its three parts
+    if(false)
+#endif
     for(uint32_t u = wave_id; u < prefix[32] * chunks_w; u += n_waves)
     {
         const uint32_t entry = u / chunks_w;
@@ -1273,10 +1282,19 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
     // (C)
     constexpr int ROWS = 8;
     const uint32_t row_blocks = uint32_t(H + ROWS - 1) / ROWS;
-    for(uint32_t u = wave_id; u < chunk_prefix[32] * row_blocks; u += n_waves)
+    // A chunk of columns stays on ONE XCD (workgroups go round the XCDs: chunk c ↔ the workgroups ≡ c mod 8): a row of E under a chunk is
+    // sampled by three row blocks 2·ry apart — in one L2 the second and third find it, spread over eight they all go out to the fabric, for
+    // lines of which a chunk's columns use a fraction (150 → 130 µs at 4K; the flagged columns' taps touch most lines of E's 531 MB).
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t xcd_waves = (gridDim.x + 7u - xcd) / 8u * 4u, xcd_wave = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);
+    const uint32_t my_chunks = (chunk_prefix[32] + 7u - xcd) / 8u;
+    int ci = 0;
+#if defined(LK_SKIP) && (LK_SKIP & 2)
+    if(false)
+#endif
+    for(uint32_t u = xcd_wave; u < my_chunks * row_blocks; u += xcd_waves)
     {
-        const uint32_t chunk = u / row_blocks, rb = u % row_blocks;
-        int ci = 0;
+        const uint32_t chunk = xcd + 8u * (u / row_blocks), rb = u % row_blocks;
         prefix_walk(chunk_prefix, chunk, ci);
         const int j = int(chunk - chunk_prefix[ci]) * 64 + lane;
         if(j >= ncols[ci])
@@ -1289,22 +1307,45 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
 #pragma unroll
         for(int tx = 0; tx < 3; tx++)
             own[tx] = (w.tapx[(size_t)tx * W + x] >> ci) & 1u;
-        for(int y = int(rb) * ROWS; y < min(int(rb) * ROWS + ROWS, H); y++)
+        // Four rows at a time, all of their 36 samples in flight together (a row flagged for the candidate — focus_exact (A) — or below the image
+        // is sampled like the others, one row up at most, and not stored)
+        const uint16_t *tap_base[3]; // per tap column (per lane): the column's own line, or the candidate's plane of E
+        uint32_t tap_pitch[3];
+#pragma unroll
+        for(int tx = 0; tx < 3; tx++)
         {
-            if((w.bady[y] >> ci) & 1u)
-                continue; // focus_exact (A)
-            uint32_t sum = 0;
+            tap_base[tx] = own[tx] ? w.Ec + (size_t)tx * w.He_p * w.C_cap + cs : w.E + (size_t)ci * w.He_p * w.We_p + x + tx * rx;
+            tap_pitch[tx] = own[tx] ? uint32_t(w.C_cap) : uint32_t(w.We_p);
+        }
 #pragma unroll
-            for(int tx = 0; tx < 3; tx++)
+        for(int y4 = 0; y4 < ROWS; y4 += 4)
+        {
+            const int yb = int(rb) * ROWS + y4;
+            if(yb >= H) // wave-uniform
+                break;
+            uint32_t sum[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for(int ty = 0; ty < 3; ty++)
-                    sum += own[tx] ? w.Ec[((size_t)tx * w.He_p + y + ty * ry) * w.C_cap + cs] : w.E[((size_t)ci * w.He_p + y + ty * ry) * w.We_p + x + tx * rx];
-            w.K[((size_t)ci * H + y) * W + x] = static_cast<uint16_t>(encode(sum));
+            for(int r = 0; r < 4; r++)
+            {
+                const uint32_t y = uint32_t(min(yb + r, H - 1));
+#pragma unroll
+                for(int tx = 0; tx < 3; tx++)
+#pragma unroll
+                    for(int ty = 0; ty < 3; ty++)
+                        sum[r] += tap_base[tx][(y + uint32_t(ty * ry)) * tap_pitch[tx]];
+            }
+#pragma unroll
+            for(int r = 0; r < 4; r++)
+                if(yb + r < H && !((w.bady[yb + r] >> ci) & 1u))
+                    w.K[((size_t)ci * H + yb + r) * W + x] = static_cast<uint16_t>(encode(sum[r]));
         }
     }
     // (A') pairs flagged on both axes whose row and column both have a line slot: focus_exact left the corner taps' partial sum in K;
     // the other taps come from the row's own lines (ty flagged), the column's own lines (tx flagged) or E (neither)
     int ai = 0;
+#if defined(LK_SKIP) && (LK_SKIP & 4)
+    if(false)
+#endif
     for(uint32_t entry = wave_id; entry < prefix[32]; entry += n_waves)
     {
         prefix_walk(prefix, entry, ai);

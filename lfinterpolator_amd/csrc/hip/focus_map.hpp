@@ -472,6 +472,74 @@ __global__ void __launch_bounds__(256) focus_filter(const KernelArgs a)
     reinterpret_cast<uint32_t *>(a.maps)[(size_t)W * H + (size_t)y * W + x] = m | (m << 8) | (m << 16) | 0xff000000u;
 }
 
+// focus_filter from LDS (round 5).  The box mean sums integers 0…255 — exact in fp32 in any order while the window holds fewer than 65,793 taps —
+// so the sum is taken separably: a workgroup stages the low bytes of map 0 under its 64 × 32 tile plus the window's reach ((64 + 2·rx) ×
+// (32 + 2·ry) values, clamped per tap like the reference's loops), sums 2·rx of them per element along x, then walks down its columns with a
+// running sum of 2·ry of those.  One dword load per staged pixel instead of 4·rx·ry per output pixel (16 at the 4K configuration: the plain
+// kernel runs at the L1's rate, 0.13 ms for an 8 MB map).  Both LDS arrays hold DWORDS: with bytes and u16 the LDS was busy 72 % of the run
+// time at 28 cycles per wave-access (sub-dword accesses of neighbouring lanes serialise) and the kernel took 60 µs.  The host checks
+// rx, ry ≤ 128 and the LDS size; larger windows take focus_filter.
+constexpr int FF_TW = 64, FF_TH = 32;
+inline size_t focus_filter_tiled_lds(const int rx, const int ry) { return 4u * (size_t(FF_TW + 2 * rx) + FF_TW) * size_t(FF_TH + 2 * ry); }
+
+__global__ void __launch_bounds__(256) focus_filter_tiled(const KernelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t ff_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W = a.width, H = a.height;
+    const int rx = max(a.radius_x / 10, 1), ry = max(a.radius_y / 10, 1); // ≥1: SURVEY.md defect D6
+    const int PW = FF_TW + 2 * rx, PH = FF_TH + 2 * ry;
+    const int x0 = blockIdx.x * FF_TW, y0 = a.map_y0 + blockIdx.y * FF_TH;
+    const int y_end = min(H, a.map_y0 + a.map_rows);
+    uint32_t *const vals = ff_lds, *const hsum = ff_lds + PW * PH;
+    const uint32_t *map0 = reinterpret_cast<const uint32_t *>(a.maps);
+    // (the staged region is walked linearly by the whole workgroup, twelve elements per thread whose loads are all issued before the first value
+    // is stored: one memory latency per tile at the usual radii, not one per row)
+    constexpr int STAGE_N = 12;
+    const int n_stage = PW * PH;
+    const float inv_pw = 1.0f / static_cast<float>(PW);
+    for(int base = threadIdx.x; base < n_stage; base += 256 * STAGE_N)
+    {
+        uint32_t px[STAGE_N];
+#pragma unroll
+        for(int k = 0; k < STAGE_N; k++)
+        {
+            const int idx = min(base + 256 * k, n_stage - 1); // (elements past the region: a harmless repeat of its last one, not stored)
+            int r = static_cast<int>(static_cast<float>(idx) * inv_pw); // idx / PW, within one
+            r += (r + 1) * PW <= idx ? 1 : (r * PW > idx ? -1 : 0);
+            px[k] = map0[(size_t)clampi(y0 - ry + r, 0, H - 1) * W + clampi(x0 - rx + idx - r * PW, 0, W - 1)];
+        }
+#pragma unroll
+        for(int k = 0; k < STAGE_N; k++)
+            if(base + 256 * k < n_stage)
+                vals[base + 256 * k] = px[k] & 0xffu;
+    }
+    __syncthreads();
+    for(int r = wave; r < PH; r += 4)
+    {
+        uint32_t s = 0;
+#pragma unroll 4
+        for(int j = 0; j < 2 * rx; j++)
+            s += vals[r * PW + lane + j];
+        hsum[r * FF_TW + lane] = s;
+    }
+    __syncthreads();
+    const int x = x0 + lane, r0 = wave * (FF_TH / 4);
+    if(x >= W || y0 + r0 >= y_end)
+        return;
+    uint32_t s = 0;
+#pragma unroll 4
+    for(int j = 0; j < 2 * ry; j++)
+        s += hsum[(r0 + j) * FF_TW + lane];
+    const float count = static_cast<float>(4 * rx * ry);
+    for(int i = 0; i < FF_TH / 4 && y0 + r0 + i < y_end; i++)
+    {
+        const uint32_t m = static_cast<uint32_t>(roundf(__fdiv_rn(static_cast<float>(s), count))) & 0xffu;
+        reinterpret_cast<uint32_t *>(a.maps)[(size_t)W * H + (size_t)(y0 + r0 + i) * W + x] = m | (m << 8) | (m << 16) | 0xff000000u;
+        s += hsum[(r0 + i + 2 * ry) * FF_TW + lane] - hsum[(r0 + i) * FF_TW + lane];
+    }
+}
+
 // focusCoords dump for the integer-warp parity test (src/kernels.cu:72-82): unclamped coordinates of image g
 __global__ void __launch_bounds__(256) dump_coords(const KernelArgs a, const int g, const int all_focus, lfi_int2 *__restrict__ out)
 {

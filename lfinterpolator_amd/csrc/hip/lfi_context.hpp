@@ -40,7 +40,7 @@ struct lfi_ctx
     hipEvent_t ev_uploads = nullptr;
     // side stream of the factored focus-map estimate (its small passes overlap the large ones), created on first use
     hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_pad = nullptr, ev_join = nullptr, ev_range = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_pad = nullptr, ev_join = nullptr;
     // the focus map's filter (map 0 → map 1) runs on the side stream behind the pick: an all-focus TEN_WM render, which reads map 0
     // (src/kernels.cu:430), does not wait for it; whatever reads map 1 or writes either map joins it first (join_filter)
     hipEvent_t ev_pick = nullptr, ev_filter = nullptr;

@@ -136,8 +136,8 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool di
     lfi::FocusPatch *patches = reinterpret_cast<lfi::FocusPatch *>(base + o_patches);
     // Two streams: the plan and the flagged-pair passes are small, latency-bound kernels; they run beside the padded copy
     // and the range pass (bandwidth / VALU bound) instead of in front of them.
-    //   main:  plan_shifts ─┬─ pad ─┬─ range ──────────────────────────┬──────────────┬─ pick (→ filter, by the caller)
-    //   aux:                └─ flags → lists → prefix ─┴─ {lines_rows, lines_cols, exact} ─┴─ line_keys ─┘
+    //   main:  plan_shifts ─┬─ pad ─┬─ range ───────────────────────────────────────────┬─ line_keys → pick (→ filter, by the caller)
+    //   aux:                └─ flags → lists → prefix ─┴─ {lines_rows, lines_cols, exact} ─┘
     if(!ctx->aux_stream)
     {
         int prio_low = 0, prio_high = 0; // numerically lower = higher priority: the small passes should not queue behind the big ones
@@ -146,7 +146,6 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool di
         LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pad, hipEventDisableTiming));
         LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        LFI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_range, hipEventDisableTiming));
     }
     hipStream_t st = ctx->stream;
     hipStream_t aux = ctx->aux_stream;
@@ -196,7 +195,6 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool di
         const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(tiles_x, tiles_y, GROUPS) : tiles_x * tiles_y * GROUPS;
         hipLaunchKernelGGL(lfi::focus_range<CPW>, dim3(nblocks), dim3(256), 0, st, a, w, nblocks, striped);
     }
-    LFI_HIP(ctx, hipEventRecord(ctx->ev_range, st));
     LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_fork, 0));
     LFI_HIP(ctx, hipMemsetAsync(w.badx, 0, o_cols - o_badx, aux)); // badx, bady, tapx, tapy are adjacent
     hipLaunchKernelGGL(lfi::focus_plan_flags, dim3((std::max(W, H) + 255) / 256, lfi::FOCUS_STEPS, 2), dim3(256), 0, aux, a, w);
@@ -212,10 +210,12 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool di
         hipLaunchKernelGGL(lfi::focus_flagged, dim3(3 * per_pass), dim3(256), 0, aux, a, w, per_pass, 0u);
 #endif
     }
-    LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_range, 0)); // the keys of single-axis pairs take their unflagged taps from E
-    hipLaunchKernelGGL(lfi::focus_line_keys, dim3(ctx->cu_count * 8), dim3(256), 0, aux, a, w);
+    // The keys of single-axis pairs take their unflagged taps from E: focus_line_keys runs behind BOTH streams' work.  On the main stream —
+    // the flagged passes end before the range pass does, so the join is an event already signalled, and the keys, the pick and whatever the
+    // caller enqueues next follow the range pass in one queue (on the side stream they cost two more hops between queues, ≈ 10 µs each).
     LFI_HIP(ctx, hipEventRecord(ctx->ev_join, aux));
     LFI_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+    hipLaunchKernelGGL(lfi::focus_line_keys, dim3(ctx->cu_count * 8), dim3(256), 0, st, a, w);
     {
         // two pixels per lane need dword-aligned sample pairs: even radius_x (the reference's is)
         const int ppl = (rx % 2 == 0 && W >= 2) ? 2 : 1;

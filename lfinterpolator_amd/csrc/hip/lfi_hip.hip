@@ -114,8 +114,6 @@ int lfi_destroy(lfi_ctx *ctx)
         (void)hipEventDestroy(ctx->ev_pad);
     if(ctx->ev_join)
         (void)hipEventDestroy(ctx->ev_join);
-    if(ctx->ev_range)
-        (void)hipEventDestroy(ctx->ev_range);
     if(ctx->ev_pick)
         (void)hipEventDestroy(ctx->ev_pick);
     if(ctx->ev_filter)
@@ -757,6 +755,17 @@ int lfi_views_device_ptr(lfi_ctx *ctx, void **out_ptr, size_t *out_bytes)
     return LFI_OK;
 }
 
+// map 1 = the box mean of map 0 over the rows a.map_y0 … + a.map_rows: from LDS (focus_filter_tiled) when the window allows it
+static void launch_focus_filter(lfi_ctx *ctx, const lfi::KernelArgs &a, hipStream_t st)
+{
+    const int rx = std::max(ctx->radius[0] / 10, 1), ry = std::max(ctx->radius[1] / 10, 1);
+    const size_t lds = lfi::focus_filter_tiled_lds(rx, ry);
+    if(rx <= 128 && ry <= 128 && lds <= 64u * 1024u)
+        hipLaunchKernelGGL(lfi::focus_filter_tiled, dim3((ctx->width + lfi::FF_TW - 1) / lfi::FF_TW, (a.map_rows + lfi::FF_TH - 1) / lfi::FF_TH), dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL(lfi::focus_filter, dim3((ctx->width + 63) / 64, (a.map_rows + 3) / 4), dim3(256), 0, st, a);
+}
+
 int lfi_focus_map(lfi_ctx *ctx)
 {
     if(!ctx)
@@ -797,7 +806,7 @@ int lfi_focus_map(lfi_ctx *ctx)
         LFI_HIP(ctx, hipGetLastError());
         a.map_y0 = ctx->out_y0;
         a.map_rows = ctx->out_rows;
-        hipLaunchKernelGGL(lfi::focus_filter, dim3((ctx->width + 63) / 64, (ctx->out_rows + 3) / 4), dim3(256), 0, ctx->stream, a);
+        launch_focus_filter(ctx, a, ctx->stream);
         LFI_HIP(ctx, hipGetLastError());
         return LFI_OK;
     }
@@ -829,13 +838,13 @@ int lfi_focus_map(lfi_ctx *ctx)
         }
         LFI_HIP(ctx, hipEventRecord(ctx->ev_pick, ctx->stream));
         LFI_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_pick, 0));
-        hipLaunchKernelGGL(lfi::focus_filter, pixel_grid(ctx), dim3(256), 0, ctx->aux_stream, a);
+        launch_focus_filter(ctx, a, ctx->aux_stream);
         LFI_HIP(ctx, hipGetLastError());
         LFI_HIP(ctx, hipEventRecord(ctx->ev_filter, ctx->aux_stream));
         ctx->filter_pending = true;
         return LFI_OK;
     }
-    hipLaunchKernelGGL(lfi::focus_filter, pixel_grid(ctx), dim3(256), 0, ctx->stream, a);
+    launch_focus_filter(ctx, a, ctx->stream);
     LFI_HIP(ctx, hipGetLastError());
     return LFI_OK;
 }

@@ -501,6 +501,28 @@ def test_focus_map_realistic_geometry(radius, gpu, oracle_c):
 
 
 
+@pytest.mark.parametrize("case", [(150, 70, (37, 25)), (333, 90, (100, 60)), (64, 32, (19, 9)), (65, 33, (20, 20)), (70, 40, (1290, 30)), (90, 50, (1000, 700))],
+                         ids=lambda c: "%dx%d_r%dx%d" % (c[0], c[1], c[2][0], c[2][1]))
+def test_focus_filter_window_sizes(case, gpu, oracle_c):
+    """Map 1 = the box mean of map 0 over (2·radius/10)² taps (src/kernels.cu:260-280), clamped at the borders: windows of 2 × 2 up to 20 × 12
+    taps from LDS (focus_filter_tiled: separable integer sums), tiles cut by the right and lower border, and windows too wide for the tiled
+    kernel's counters (radius 1290) or for the LDS (1000 × 700): the plain kernel — byte for byte the oracle's filter of the same map 0."""
+    W, H, rad = case
+    cols, rows = 3, 3
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.2, 0.3, 3.0, 1.783, 2)
+    hp.block_radius = np.array(rad, np.int32)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, 5 + W)
+    lf[..., 3] = 255
+    ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    ctx.focus_map()
+    ctx.sync()
+    map0 = ctx.download_map(0)
+    assert len(np.unique(map0)) > 4
+    want1 = oracle_c.focus_filter(map0, hp.block_radius)
+    assert (ctx.download_map(1) == want1).all(), int((ctx.download_map(1) != want1).sum())
+    ctx.close()
+
+
 @pytest.mark.parametrize("case", [(1, 1, 64, 20, 0.2, 0.3, None), (1, 2, 100, 33, 0.1, 0.2, None), (2, 1, 7, 5, 0.3, 0.5, (1, 1)), (3, 3, 1024, 70, 0.22, 0.17, None),
                                   (8, 8, 2048, 96, 0.05, 0.04, (20, 10)), (15, 15, 640, 64, 0.22, 0.17, (6, 4)), (6, 6, 513, 40, -0.3, 0.6, None),
                                   (9, 9, 300, 48, 0.0, 1.0, (11, 5)), (4, 4, 4096, 36, 0.22, 0.17, None), (5, 3, 190, 130, 0.5, 0.01, None)],
