@@ -535,8 +535,14 @@ __global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const Foc
 // (buffer_load_format_d16_xyzw, format 8_8_8_8 UINT: exact from any byte address, but 16 cycles per wave-load of ONE pixel per lane), every
 // wave loading and reducing in turn (the phases added up), one workgroup per tile × group (a workgroup that owns the LDS cannot overlap
 // its successor's start-up: 2.5 → 1.8 ms when made persistent).
-constexpr int FRT_TW = 64;                          // tile: extended columns (one per lane); rows: four per wave
-constexpr int FRT_NW = 8, FRT_TH = 4 * FRT_NW;      // waves per workgroup, tile rows
+#ifndef FRT_RPW
+#define FRT_RPW 4 // rows of the tile per reducing wave: 4 (eight reducing waves, tile 64 × 32) or 2 (twelve, tile 64 × 24)
+#endif
+#ifndef FRT_DEPTH
+#define FRT_DEPTH 2 // units (four LDS reads each) a reducing wave keeps in flight
+#endif
+constexpr int FRT_TW = 64;                          // tile: extended columns (one per lane); rows: FRT_RPW per reducing wave
+constexpr int FRT_NW = FRT_RPW == 4 ? 8 : 12, FRT_TH = FRT_RPW * FRT_NW; // reducing waves per workgroup, tile rows
 constexpr int FRT_MAX_DX = 32, FRT_MAX_DY = 18;     // the largest span of a view's shifts within a candidate group
 constexpr int FRT_PW = FRT_TW + FRT_MAX_DX;         // a view's patch in LDS: pixels per row (the row pitch) …
 constexpr int FRT_PR = FRT_TH + FRT_MAX_DY;         // … × rows, at most
@@ -758,7 +764,8 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
     }
     // ---- a reducing wave: rows 4·wave … 4·wave + 3 of the tile, column lane
     // LDS address of this lane's column in the first of its four rows
-    const uint32_t rd_addr = uint32_t(uintptr_t((__attribute__((address_space(3))) void *)lds)) + uint32_t(4 * wave * FRT_PW + lane) * 8u;
+    constexpr int PAIRS = FRT_RPW / 2; // row pairs per reducing lane
+    const uint32_t rd_addr = uint32_t(uintptr_t((__attribute__((address_space(3))) void *)lds)) + uint32_t(FRT_RPW * wave * FRT_PW + lane) * 8u;
     for(uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x)
     {
     uint32_t tx, ty, group;
@@ -766,11 +773,11 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
         continue;
     const focus_const_u32_ptr plan_words = (focus_const_u32_ptr)(uintptr_t)(plans + group * FOCUS_MAX_IDS);
     // accumulators per candidate: [R,G] of the four rows, [B,B'] of the two row pairs — running minima and maxima
-    u16x2 lo[CPW][6], hi[CPW][6];
+    u16x2 lo[CPW][3 * PAIRS], hi[CPW][3 * PAIRS];
 #pragma unroll
     for(int c = 0; c < CPW; c++)
 #pragma unroll
-        for(int r = 0; r < 6; r++)
+        for(int r = 0; r < 3 * PAIRS; r++)
         {
             lo[c][r] = as_u16x2(0x00ff00ffu);
             hi[c][r] = as_u16x2(0u);
@@ -815,13 +822,17 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
                 asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[3]) : "v"(pb), "n"(3 * FRT_PW * 8));
             }
         };
-        auto reduce = [&](const int c, const int pair, u32x2 (&q)[4], const bool more_in_flight) {
-            if(more_in_flight)
+        auto reduce = [&](const int c, const int pair, u32x2 (&q)[4], const int units_in_flight) {
+            if(units_in_flight >= 3)
+                asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+            else if(units_in_flight == 2)
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+            else if(units_in_flight == 1)
                 asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
             else
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
             // accumulators of the pair: [R,G] of its two rows, [B,B']
-            const int r0 = 2 * pair, r1 = 2 * pair + 1, rb = 4 + pair;
+            const int r0 = 2 * pair, r1 = 2 * pair + 1, rb = 2 * PAIRS + pair;
             lo[c][r0] = min3_bytes(lo[c][r0], as_u16x2(q[0].x), as_u16x2(q[2].x));
             hi[c][r0] = max3_bytes(hi[c][r0], as_u16x2(q[0].x), as_u16x2(q[2].x));
             lo[c][r1] = min3_bytes(lo[c][r1], as_u16x2(q[1].x), as_u16x2(q[3].x));
@@ -836,38 +847,42 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
         half ^= 2u * FRT_VIEW_B;
         continue;
 #endif
-        u32x2 q[2][4];
-        uint32_t pa = slot_addr(0, 0), pb = slot_addr(0, 1);
-        read4(pa, pb, 0, q[0]);
+        constexpr int UNITS = PAIRS * CPW, D = FRT_DEPTH;
+        static_assert(D >= 2 && D <= 4 && D <= UNITS, "two to four units in flight (lgkmcnt counts to 15)");
+        u32x2 q[D][4];
+        uint32_t pa = 0u, pb = 0u;
+        auto issue_unit = [&](const int u) { // the reads of unit u = (candidate u / PAIRS, row pair u % PAIRS)
+            if(u % PAIRS == 0) // the unit starts a candidate
+                pa = slot_addr(u / PAIRS, 0), pb = slot_addr(u / PAIRS, 1);
+            read4(pa, pb, u % PAIRS, q[u % D]);
+        };
 #pragma unroll
-        for(int u = 0; u < 2 * CPW; u++)
+        for(int u = 0; u < D - 1; u++)
+            issue_unit(u);
+#pragma unroll
+        for(int u = 0; u < UNITS; u++)
         {
-            const int c = u >> 1, pair = u & 1;
-            if(u + 1 < 2 * CPW)
-            {
-                if(pair == 1) // the next unit starts the next candidate
-                    pa = slot_addr(c + 1, 0), pb = slot_addr(c + 1, 1);
-                read4(pa, pb, pair ^ 1, q[(u + 1) & 1]);
-            }
-            reduce(c, pair, q[u & 1], u + 1 < 2 * CPW);
+            if(u + D - 1 < UNITS)
+                issue_unit(u + D - 1);
+            reduce(u / PAIRS, u % PAIRS, q[u % D], (UNITS - 1 - u) < (D - 1) ? (UNITS - 1 - u) : (D - 1));
         }
         half ^= 2u * FRT_VIEW_B;
     }
     // E: 16·range + (FLT_MIN tap ? 1 : 0) per pixel (focus_map.hpp); a lane holds rows 4·wave … 4·wave + 3 of its column
-    const int ey0 = int(ty) * FRT_TH + 4 * wave;
+    const int ey0 = int(ty) * FRT_TH + FRT_RPW * wave;
     const uint32_t ex = tx * FRT_TW + lane;
 #pragma unroll
     for(int c = 0; c < CPW; c++)
 #pragma unroll
-        for(int u = 0; u < 2; u++)
+        for(int u = 0; u < PAIRS; u++)
         {
-            const u16x2 d0 = hi[c][2 * u] - lo[c][2 * u], d1 = hi[c][2 * u + 1] - lo[c][2 * u + 1], db = hi[c][4 + u] - lo[c][4 + u];
+            const u16x2 d0 = hi[c][2 * u] - lo[c][2 * u], d1 = hi[c][2 * u + 1] - lo[c][2 * u + 1], db = hi[c][2 * PAIRS + u] - lo[c][2 * PAIRS + u];
             // (row 0, row 1) pairs per channel: low halves = R, high halves = G of the two rows
             const u16x2 dr = as_u16x2(__builtin_amdgcn_perm(as_u32(d1), as_u32(d0), 0x05040100u)), dg = as_u16x2(__builtin_amdgcn_perm(as_u32(d1), as_u32(d0), 0x07060302u));
             const u16x2 dmax = __builtin_elementwise_max(__builtin_elementwise_max(dr, dg), db);
             const u16x2 hr = as_u16x2(__builtin_amdgcn_perm(as_u32(hi[c][2 * u + 1]), as_u32(hi[c][2 * u]), 0x05040100u));
             const u16x2 hg = as_u16x2(__builtin_amdgcn_perm(as_u32(hi[c][2 * u + 1]), as_u32(hi[c][2 * u]), 0x07060302u));
-            const u16x2 hmin = __builtin_elementwise_min(__builtin_elementwise_min(hr, hg), hi[c][4 + u]);
+            const u16x2 hmin = __builtin_elementwise_min(__builtin_elementwise_min(hr, hg), hi[c][2 * PAIRS + u]);
             const u16x2 nz = __builtin_elementwise_min(as_u16x2(as_u32(dmax) | as_u32(hmin)), as_u16x2(0x00010001u));
             const uint32_t enc = (as_u32(dmax) << 4) + (0x00010001u - as_u32(nz)); // per half: 16·range ≤ 4080, no carry
             const int ey = ey0 + 2 * u;
@@ -1504,6 +1519,166 @@ __global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const Focu
     }
 #pragma unroll
     for(int j = 0; j < PPL; j++)
+        if(x + j < W)
+        {
+            const float best_f = focus_candidate(a, best_i[j]);
+            const float normalized = __fdiv_rn(best_f - a.focus, a.range);
+            const uint32_t m = static_cast<uint32_t>(roundf(normalized * 255.0f)) & 0xffu;
+            reinterpret_cast<uint32_t *>(a.maps)[(size_t)y * W + x + j] = m | (m << 8) | (m << 16) | 0xff000000u;
+        }
+}
+
+// focus_pick with the tap block taken apart (round 5): the dispersion of a pixel is Σ_ty Σ_tx E(x + tx·rx, y + ty·ry) — a vertical three-sum
+// V(x) = Σ_ty E(x, y + ty·ry) followed by a horizontal one over V(x), V(x + rx), V(x + 2rx).  A wave owns 128 adjacent pixels of one row (two
+// per lane, as focus_pick<2>); per candidate it loads the three tap rows ONCE over the columns its pixels' taps span — the 128 columns of its
+// own pixels by all lanes, the 2·rx columns behind them by the first rx lanes — sums them vertically (packed u16) and fetches V(x + rx),
+// V(x + 2rx) from the lanes rx/2 and rx further on (ds_bpermute_b32: the LDS crossbar, no memory): 3 full + 3 partial wave-loads per candidate
+// instead of 9 full ones.  focus_pick<2> runs at the L1's tag rate (4-byte loads at 4-byte alignment: 5.6 tag accesses per load, the L1 busy
+// 64 % of the kernel); the sums are the same integers in any order, so the map is bit-identical.  Needs an even radius_x ≤ 64 (the reference's
+// is even, src/interpolator.cu:143-146; 64 ↔ images up to 6,400 pixels wide) — else focus_pick<PPL>.  Same block → pixel mapping (stripes per XCD).
+constexpr int FPS_WAVES = 16; // waves per workgroup of focus_pick_sep
+// rows of workgroups of focus_pick_sep: bands of FPS_WAVES·ry rows of the map, ry workgroups each
+__host__ __device__ __forceinline__ uint32_t focus_pick_sep_block_rows(const int H, const int ry)
+{
+    const int d = ry > 0 ? ry : 1; // (a zero radius: the taps coincide; any row distance serves)
+    return uint32_t((H + FPS_WAVES * d - 1) / (FPS_WAVES * d)) * uint32_t(d);
+}
+
+__global__ void __launch_bounds__(64 * FPS_WAVES) focus_pick_sep(const KernelArgs a, const FocusWork w)
+{
+    const int W = a.width, H = a.height;
+    const uint32_t blocks_x = uint32_t(W + 127) / 128u;
+    const uint32_t bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
+    const int lane = int(threadIdx.x & 63);
+    const int x0 = int(bx) * 128, x = x0 + 2 * lane;
+    const int rx = a.radius_x, ry = a.radius_y;
+    // The sixteen waves of a workgroup take rows ry APART (row j of a band of 16·ry rows, then j + ry, j + 2·ry, …): the tap rows of wave k
+    // are the rows of waves k, k + 1, k + 2, so a workgroup reads 18 rows of E for 16 rows of the map — from the fabric once; the other two uses
+    // are hits on its own CU at about the same time.  Workgroups in row-major order.  (Four ADJACENT rows per workgroup in stripes per XCD,
+    // focus_pick<2>'s mapping, leave the re-use of a row of E — ry and 2·ry rows further down the stripe — to the XCD's L2: FETCH_SIZE 880 MB
+    // for E's 531 MB, 267 µs at 4K whatever the kernel did per wave; 16 / 8 / 4 waves ry apart: 238 / 253 / 272 µs —
+    // profiles/r05_focus_pick_experiments.txt.)
+    const int rd = ry > 0 ? ry : 1;
+    const int band = int(by) / rd, j = int(by) - band * rd;
+    const int y = __builtin_amdgcn_readfirstlane((band * FPS_WAVES + int(threadIdx.x >> 6)) * rd + j);
+    if(y >= H) // wave-uniform
+        return;
+    // flags and K are indexed by image columns: lanes past the right edge take column 0 and store nothing.  E is indexed by EXTENDED columns
+    // and every lane loads its own (x + 1 < We_p: We_p ≥ W + 2·rx rounded up to 256): the lanes past the edge hold taps of the lanes before it
+    const int xs = x < W ? x : 0;
+    const uint32_t flagged_y = __builtin_amdgcn_readfirstlane(w.bady[y]);
+    uint32_t flagged[2];
+    flagged[0] = w.badx[xs] | flagged_y;
+    flagged[1] = w.badx[xs + 1] | flagged_y;
+    const bool wave_flagged = __builtin_amdgcn_ballot_w64((flagged[0] | flagged[1]) != 0u) != 0ull;
+    // the candidates with a flagged pair anywhere in this wave: K is read for those only (the others read candidate 0's resident lines)
+    uint32_t wave_mask = 0u;
+    if(wave_flagged)
+    {
+        uint32_t m = flagged[0] | flagged[1];
+#pragma unroll
+        for(int off = 32; off >= 1; off >>= 1)
+            m |= uint32_t(__shfl_xor(int(m), off));
+        wave_mask = __builtin_amdgcn_readfirstlane(m);
+    }
+    // byte offsets inside a candidate's plane of E: this lane's two pixels in the three tap rows, and (lanes below rx) two of the 2·rx columns
+    // behind the wave's 128; the other lanes' offset is out of the descriptor's range — a buffer load returns 0 for it without a memory access
+    uint32_t main_off[3], extra_off[3];
+#pragma unroll
+    for(int ty = 0; ty < 3; ty++)
+    {
+        const uint32_t row = uint32_t(y + ty * ry) * uint32_t(w.We_p);
+        main_off[ty] = (row + uint32_t(x)) * 2u;
+        extra_off[ty] = lane < rx ? (row + uint32_t(x0 + 128 + 2 * lane)) * 2u : 0xfffffff0u;
+    }
+    // lane l's taps tx = 1, 2 are lanes l + rx/2 and l + rx of the wave's 64 + rx lanes-worth of V: beyond lane 63 they are in the extra part
+    const int src1 = lane + (rx >> 1), src2 = lane + rx;
+    const int idx1 = 4 * (src1 & 63), idx2 = 4 * (src2 & 63);
+    const bool own1 = src1 < 64, own2 = src2 < 64;
+    const uint32_t e_plane_bytes = uint32_t(w.He_p) * uint32_t(w.We_p) * 2u, k_plane_bytes = uint32_t(H) * uint32_t(W) * 2u; // < 2^28
+    const uint32_t k_off = (uint32_t(y) * uint32_t(W) + uint32_t(xs)) * 2u;
+    uint32_t best_key[2] = {0xffffffffu, 0xffffffffu};
+    int best_i[2] = {0, 0};
+    // Candidates in groups of four: a group's 24 loads of E (and its keys of K) are issued together, then summed.  One to sixteen candidates per
+    // group, one or two groups in flight, 40 to 154 registers, three to eight workgroups per CU: 262-272 µs at 4K whichever — and the same with
+    // E's rows interleaved by candidate, with K read in full, with nine full loads per candidate (focus_pick<2>): profiles/r05_notes.md §5.
+    constexpr int G = 4;
+    static_assert(FOCUS_STEPS % G == 0, "whole groups");
+    auto load_group = [&](const int i0, uint32_t (&em)[G][3], uint32_t (&ee)[G][3], uint32_t (&kx)[G][2], auto exact_tag) {
+#pragma unroll
+        for(int g = 0; g < G; g++)
+        {
+            const __amdgpu_buffer_rsrc_t re =
+                __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(w.E) + (size_t)(i0 + g) * e_plane_bytes, 0, int(e_plane_bytes), 0x00020000);
+#pragma unroll
+            for(int ty = 0; ty < 3; ty++)
+            {
+                em[g][ty] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(re, int(main_off[ty]), 0, 0));
+                ee[g][ty] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(re, int(extra_off[ty]), 0, 0));
+            }
+            if constexpr(decltype(exact_tag)::value)
+            {
+                const size_t kplane = ((wave_mask >> (i0 + g)) & 1u) ? size_t(i0 + g) : size_t(0); // wave-uniform
+                const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(w.K) + kplane * k_plane_bytes, 0, int(k_plane_bytes), 0x00020000);
+                kx[g][0] = uint32_t(__builtin_amdgcn_raw_buffer_load_b16(rk, int(k_off), 0, 0));
+                kx[g][1] = uint32_t(__builtin_amdgcn_raw_buffer_load_b16(rk, int(k_off + 2u), 0, 0));
+            }
+        }
+    };
+    auto reduce_group = [&](const int i0, const uint32_t (&em)[G][3], const uint32_t (&ee)[G][3], const uint32_t (&kx)[G][2], auto exact_tag) {
+        u16x2 vm[G], ve[G]; // V of this lane's pixel pair, of its extra pair: 3 · 4081 per half
+#pragma unroll
+        for(int g = 0; g < G; g++)
+        {
+            vm[g] = as_u16x2(em[g][0]) + as_u16x2(em[g][1]) + as_u16x2(em[g][2]);
+            ve[g] = as_u16x2(ee[g][0]) + as_u16x2(ee[g][1]) + as_u16x2(ee[g][2]);
+        }
+        uint32_t t1m[G], t1e[G], t2m[G], t2e[G];
+#pragma unroll
+        for(int g = 0; g < G; g++)
+        {
+            t1m[g] = uint32_t(__builtin_amdgcn_ds_bpermute(idx1, int(as_u32(vm[g]))));
+            t1e[g] = uint32_t(__builtin_amdgcn_ds_bpermute(idx1, int(as_u32(ve[g]))));
+            t2m[g] = uint32_t(__builtin_amdgcn_ds_bpermute(idx2, int(as_u32(vm[g]))));
+            t2e[g] = uint32_t(__builtin_amdgcn_ds_bpermute(idx2, int(as_u32(ve[g]))));
+        }
+#pragma unroll
+        for(int g = 0; g < G; g++)
+        {
+            const int i = i0 + g;
+            const u16x2 acc = vm[g] + as_u16x2(own1 ? t1m[g] : t1e[g]) + as_u16x2(own2 ? t2m[g] : t2e[g]); // 9 · 4081 < 65536 per half
+            const uint32_t sum[2] = {as_u32(acc) & 0xffffu, as_u32(acc) >> 16};
+#pragma unroll
+            for(int j = 0; j < 2; j++)
+            {
+                uint32_t key = sum[j] >= 16u ? (sum[j] & ~15u) : sum[j];
+                if constexpr(decltype(exact_tag)::value)
+                    key = ((flagged[j] >> i) & 1u) ? (kx[g][j] & 0xffffu) : key;
+                if(key < best_key[j]) // MinDispersion::add (src/kernels.cu:225-231): strict <
+                {
+                    best_key[j] = key;
+                    best_i[j] = i;
+                }
+            }
+        }
+    };
+    auto all_candidates = [&](auto exact_tag) {
+        uint32_t em[G][3], ee[G][3], kx[G][2];
+#pragma unroll 1
+        for(int i0 = 0; i0 < FOCUS_STEPS; i0 += G)
+        {
+            load_group(i0, em, ee, kx, exact_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            reduce_group(i0, em, ee, kx, exact_tag);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if(wave_flagged)
+        all_candidates(std::true_type{});
+    else
+        all_candidates(std::false_type{});
+#pragma unroll
+    for(int j = 0; j < 2; j++)
         if(x + j < W)
         {
             const float best_f = focus_candidate(a, best_i[j]);

@@ -130,6 +130,7 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool di
     w.Er = reinterpret_cast<uint16_t *>(base + o_Er);
     w.Ec = reinterpret_cast<uint16_t *>(base + o_Ec);
     w.E = reinterpret_cast<uint16_t *>(base + o_E);
+    const bool e_32bit = sizeof(uint16_t) * (size_t)w.He_p * w.We_p < ((size_t)1 << 31); // focus_pick_sep: a candidate's plane of E behind one buffer descriptor
     w.K = reinterpret_cast<uint16_t *>(base + o_K);
     w.deltas = reinterpret_cast<int64_t *>(base + o_deltas);
     w.pad = reinterpret_cast<uint32_t *>(base + o_pad);
@@ -222,7 +223,14 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool di
         const uint32_t blocks_x = uint32_t((W + 64 * ppl - 1) / (64 * ppl)), blocks_y = uint32_t((H + 3) / 4);
         const int striped = blocks_x >= 8;
         const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(blocks_x, blocks_y, 1u) : blocks_x * blocks_y;
-        if(ppl == 2)
+        // the tap block taken apart (focus_pick_sep): even radius_x of at most 64; variant "factored_direct" keeps focus_pick<2>, the other implementation
+        if(ppl == 2 && rx <= 64 && e_32bit && !direct_range)
+        {
+            // (row-major order of the workgroups, not stripes per XCD: this kernel's re-use of E's rows happens inside a workgroup)
+            const uint32_t nb = blocks_x * lfi::focus_pick_sep_block_rows(H, ry);
+            hipLaunchKernelGGL(lfi::focus_pick_sep, dim3(nb), dim3(64 * lfi::FPS_WAVES), 0, st, a, w);
+        }
+        else if(ppl == 2)
             hipLaunchKernelGGL(lfi::focus_pick<2>, dim3(nblocks), dim3(256), 0, st, a, w, striped);
         else
             hipLaunchKernelGGL(lfi::focus_pick<1>, dim3(nblocks), dim3(256), 0, st, a, w, striped);
