@@ -1537,133 +1537,159 @@ __global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const Focu
 // 64 % of the kernel); the sums are the same integers in any order, so the map is bit-identical.  Needs an even radius_x ≤ 64 (the reference's
 // is even, src/interpolator.cu:143-146; 64 ↔ images up to 6,400 pixels wide) — else focus_pick<PPL>.  Same block → pixel mapping (stripes per XCD).
 constexpr int FPS_WAVES = 16; // waves per workgroup of focus_pick_sep
-// rows of workgroups of focus_pick_sep: bands of FPS_WAVES·ry rows of the map, ry workgroups each
+#ifndef FPS_R
+#define FPS_R 2 // (measurement builds: 1 … 4)
+#endif
+constexpr int FPS_ROWS = FPS_R; // rows of the map per wave (radius_y apart): 1 / 2 / 3 / 4 → 239 / 218 / 237 / 233 µs at 4K
+// rows of workgroups of focus_pick_sep: bands of FPS_WAVES·FPS_ROWS·ry rows of the map, ry workgroups each
 __host__ __device__ __forceinline__ uint32_t focus_pick_sep_block_rows(const int H, const int ry)
 {
     const int d = ry > 0 ? ry : 1; // (a zero radius: the taps coincide; any row distance serves)
-    return uint32_t((H + FPS_WAVES * d - 1) / (FPS_WAVES * d)) * uint32_t(d);
+    return uint32_t((H + FPS_WAVES * FPS_ROWS * d - 1) / (FPS_WAVES * FPS_ROWS * d)) * uint32_t(d);
 }
 
 __global__ void __launch_bounds__(64 * FPS_WAVES) focus_pick_sep(const KernelArgs a, const FocusWork w)
 {
+    constexpr int R = FPS_ROWS, NR = R + 2; // rows of the map per wave, rows of E it loads for them
     const int W = a.width, H = a.height;
     const uint32_t blocks_x = uint32_t(W + 127) / 128u;
     const uint32_t bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
     const int lane = int(threadIdx.x & 63);
     const int x0 = int(bx) * 128, x = x0 + 2 * lane;
     const int rx = a.radius_x, ry = a.radius_y;
-    // The sixteen waves of a workgroup take rows ry APART (row j of a band of 16·ry rows, then j + ry, j + 2·ry, …): the tap rows of wave k
-    // are the rows of waves k, k + 1, k + 2, so a workgroup reads 18 rows of E for 16 rows of the map — from the fabric once; the other two uses
-    // are hits on its own CU at about the same time.  Workgroups in row-major order.  (Four ADJACENT rows per workgroup in stripes per XCD,
-    // focus_pick<2>'s mapping, leave the re-use of a row of E — ry and 2·ry rows further down the stripe — to the XCD's L2: FETCH_SIZE 880 MB
-    // for E's 531 MB, 267 µs at 4K whatever the kernel did per wave; 16 / 8 / 4 waves ry apart: 238 / 253 / 272 µs —
-    // profiles/r05_focus_pick_experiments.txt.)
+    // A workgroup's waves and a wave's R rows are ry APART (row j of a band of 16·R·ry rows, then j + ry, j + 2·ry, …): the tap rows of a row
+    // are its own and the next two of that sequence, so a wave loads R + 2 rows of E for R rows of the map and a workgroup reads 16·R + 2 rows
+    // for 16·R — from the fabric once; the uses by the neighbouring waves are hits on its own CU at about the same time.  Workgroups in
+    // row-major order.  (Four ADJACENT rows per workgroup in stripes per XCD, focus_pick<2>'s mapping, leave the re-use of a row of E — ry and
+    // 2·ry rows further down the stripe — to the XCD's L2: FETCH_SIZE 880 MB for E's 531 MB, 267 µs at 4K whatever the kernel did per wave;
+    // 16 / 8 / 4 waves of one row each, ry apart: 238 / 253 / 272 µs — profiles/r05_focus_pick_experiments.txt.)
     const int rd = ry > 0 ? ry : 1;
-    const int band = int(by) / rd, j = int(by) - band * rd;
-    const int y = __builtin_amdgcn_readfirstlane((band * FPS_WAVES + int(threadIdx.x >> 6)) * rd + j);
-    if(y >= H) // wave-uniform
+    const int band = int(by) / rd, j0 = int(by) - band * rd;
+    const int y0 = __builtin_amdgcn_readfirstlane(((band * FPS_WAVES + int(threadIdx.x >> 6)) * R) * rd + j0);
+    if(y0 >= H) // wave-uniform
         return;
     // flags and K are indexed by image columns: lanes past the right edge take column 0 and store nothing.  E is indexed by EXTENDED columns
-    // and every lane loads its own (x + 1 < We_p: We_p ≥ W + 2·rx rounded up to 256): the lanes past the edge hold taps of the lanes before it
+    // and every lane loads its own (x + 1 < We_p: We_p ≥ W + 2·rx rounded up to 256): the lanes past the edge hold taps of the lanes before it.
+    // Rows of the wave below the image are computed like the others (their loads past a plane's end return 0) and not stored.
     const int xs = x < W ? x : 0;
-    const uint32_t flagged_y = __builtin_amdgcn_readfirstlane(w.bady[y]);
-    uint32_t flagged[2];
-    flagged[0] = w.badx[xs] | flagged_y;
-    flagged[1] = w.badx[xs + 1] | flagged_y;
-    const bool wave_flagged = __builtin_amdgcn_ballot_w64((flagged[0] | flagged[1]) != 0u) != 0ull;
+    uint32_t flagged[R][2], any_flag = 0u;
+#pragma unroll
+    for(int r = 0; r < R; r++)
+    {
+        const uint32_t flagged_y = __builtin_amdgcn_readfirstlane(w.bady[min(y0 + r * rd, H - 1)]);
+        flagged[r][0] = w.badx[xs] | flagged_y;
+        flagged[r][1] = w.badx[xs + 1] | flagged_y;
+        any_flag |= flagged[r][0] | flagged[r][1];
+    }
+    const bool wave_flagged = __builtin_amdgcn_ballot_w64(any_flag != 0u) != 0ull;
     // the candidates with a flagged pair anywhere in this wave: K is read for those only (the others read candidate 0's resident lines)
     uint32_t wave_mask = 0u;
     if(wave_flagged)
     {
-        uint32_t m = flagged[0] | flagged[1];
+        uint32_t m = any_flag;
 #pragma unroll
         for(int off = 32; off >= 1; off >>= 1)
             m |= uint32_t(__shfl_xor(int(m), off));
         wave_mask = __builtin_amdgcn_readfirstlane(m);
     }
-    // byte offsets inside a candidate's plane of E: this lane's two pixels in the three tap rows, and (lanes below rx) two of the 2·rx columns
-    // behind the wave's 128; the other lanes' offset is out of the descriptor's range — a buffer load returns 0 for it without a memory access
-    uint32_t main_off[3], extra_off[3];
+    // byte offsets inside a candidate's plane of E: this lane's two pixels in the wave's NR rows of E, and (lanes below rx) two of the 2·rx
+    // columns behind the wave's 128; the other lanes' offset is out of the descriptor's range — a buffer load returns 0 for it without a memory access
+    uint32_t main_off[NR], extra_off[NR];
 #pragma unroll
-    for(int ty = 0; ty < 3; ty++)
+    for(int q = 0; q < NR; q++)
     {
-        const uint32_t row = uint32_t(y + ty * ry) * uint32_t(w.We_p);
-        main_off[ty] = (row + uint32_t(x)) * 2u;
-        extra_off[ty] = lane < rx ? (row + uint32_t(x0 + 128 + 2 * lane)) * 2u : 0xfffffff0u;
+        const uint32_t row = uint32_t(y0 + q * ry) * uint32_t(w.We_p);
+        main_off[q] = (row + uint32_t(x)) * 2u;
+        extra_off[q] = lane < rx ? (row + uint32_t(x0 + 128 + 2 * lane)) * 2u : 0xfffffff0u;
     }
     // lane l's taps tx = 1, 2 are lanes l + rx/2 and l + rx of the wave's 64 + rx lanes-worth of V: beyond lane 63 they are in the extra part
     const int src1 = lane + (rx >> 1), src2 = lane + rx;
     const int idx1 = 4 * (src1 & 63), idx2 = 4 * (src2 & 63);
     const bool own1 = src1 < 64, own2 = src2 < 64;
     const uint32_t e_plane_bytes = uint32_t(w.He_p) * uint32_t(w.We_p) * 2u, k_plane_bytes = uint32_t(H) * uint32_t(W) * 2u; // < 2^28
-    const uint32_t k_off = (uint32_t(y) * uint32_t(W) + uint32_t(xs)) * 2u;
-    uint32_t best_key[2] = {0xffffffffu, 0xffffffffu};
-    int best_i[2] = {0, 0};
-    // Candidates in groups of four: a group's 24 loads of E (and its keys of K) are issued together, then summed.  One to sixteen candidates per
-    // group, one or two groups in flight, 40 to 154 registers, three to eight workgroups per CU: 262-272 µs at 4K whichever — and the same with
-    // E's rows interleaved by candidate, with K read in full, with nine full loads per candidate (focus_pick<2>): profiles/r05_notes.md §5.
+    uint32_t k_off[R];
+#pragma unroll
+    for(int r = 0; r < R; r++)
+        k_off[r] = (uint32_t(min(y0 + r * rd, H - 1)) * uint32_t(W) + uint32_t(xs)) * 2u;
+    uint32_t best_key[R][2];
+    int best_i[R][2];
+#pragma unroll
+    for(int r = 0; r < R; r++)
+        best_key[r][0] = best_key[r][1] = 0xffffffffu, best_i[r][0] = best_i[r][1] = 0;
+    // Candidates in groups of four: a group's loads of E (and its keys of K) are issued together, then summed.  (One row per wave: one to sixteen
+    // candidates per group, one or two groups in flight, 40 to 154 registers, three to eight workgroups per CU all took the same time.)
     constexpr int G = 4;
     static_assert(FOCUS_STEPS % G == 0, "whole groups");
-    auto load_group = [&](const int i0, uint32_t (&em)[G][3], uint32_t (&ee)[G][3], uint32_t (&kx)[G][2], auto exact_tag) {
+    auto load_group = [&](const int i0, uint32_t (&em)[G][NR], uint32_t (&ee)[G][NR], uint32_t (&kx)[G][R][2], auto exact_tag) {
 #pragma unroll
         for(int g = 0; g < G; g++)
         {
             const __amdgpu_buffer_rsrc_t re =
                 __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(w.E) + (size_t)(i0 + g) * e_plane_bytes, 0, int(e_plane_bytes), 0x00020000);
 #pragma unroll
-            for(int ty = 0; ty < 3; ty++)
+            for(int q = 0; q < NR; q++)
             {
-                em[g][ty] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(re, int(main_off[ty]), 0, 0));
-                ee[g][ty] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(re, int(extra_off[ty]), 0, 0));
+                em[g][q] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(re, int(main_off[q]), 0, 0));
+                ee[g][q] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(re, int(extra_off[q]), 0, 0));
             }
             if constexpr(decltype(exact_tag)::value)
             {
                 const size_t kplane = ((wave_mask >> (i0 + g)) & 1u) ? size_t(i0 + g) : size_t(0); // wave-uniform
                 const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(w.K) + kplane * k_plane_bytes, 0, int(k_plane_bytes), 0x00020000);
-                kx[g][0] = uint32_t(__builtin_amdgcn_raw_buffer_load_b16(rk, int(k_off), 0, 0));
-                kx[g][1] = uint32_t(__builtin_amdgcn_raw_buffer_load_b16(rk, int(k_off + 2u), 0, 0));
-            }
-        }
-    };
-    auto reduce_group = [&](const int i0, const uint32_t (&em)[G][3], const uint32_t (&ee)[G][3], const uint32_t (&kx)[G][2], auto exact_tag) {
-        u16x2 vm[G], ve[G]; // V of this lane's pixel pair, of its extra pair: 3 · 4081 per half
 #pragma unroll
-        for(int g = 0; g < G; g++)
-        {
-            vm[g] = as_u16x2(em[g][0]) + as_u16x2(em[g][1]) + as_u16x2(em[g][2]);
-            ve[g] = as_u16x2(ee[g][0]) + as_u16x2(ee[g][1]) + as_u16x2(ee[g][2]);
-        }
-        uint32_t t1m[G], t1e[G], t2m[G], t2e[G];
-#pragma unroll
-        for(int g = 0; g < G; g++)
-        {
-            t1m[g] = uint32_t(__builtin_amdgcn_ds_bpermute(idx1, int(as_u32(vm[g]))));
-            t1e[g] = uint32_t(__builtin_amdgcn_ds_bpermute(idx1, int(as_u32(ve[g]))));
-            t2m[g] = uint32_t(__builtin_amdgcn_ds_bpermute(idx2, int(as_u32(vm[g]))));
-            t2e[g] = uint32_t(__builtin_amdgcn_ds_bpermute(idx2, int(as_u32(ve[g]))));
-        }
-#pragma unroll
-        for(int g = 0; g < G; g++)
-        {
-            const int i = i0 + g;
-            const u16x2 acc = vm[g] + as_u16x2(own1 ? t1m[g] : t1e[g]) + as_u16x2(own2 ? t2m[g] : t2e[g]); // 9 · 4081 < 65536 per half
-            const uint32_t sum[2] = {as_u32(acc) & 0xffffu, as_u32(acc) >> 16};
-#pragma unroll
-            for(int j = 0; j < 2; j++)
-            {
-                uint32_t key = sum[j] >= 16u ? (sum[j] & ~15u) : sum[j];
-                if constexpr(decltype(exact_tag)::value)
-                    key = ((flagged[j] >> i) & 1u) ? (kx[g][j] & 0xffffu) : key;
-                if(key < best_key[j]) // MinDispersion::add (src/kernels.cu:225-231): strict <
+                for(int r = 0; r < R; r++)
                 {
-                    best_key[j] = key;
-                    best_i[j] = i;
+                    kx[g][r][0] = uint32_t(__builtin_amdgcn_raw_buffer_load_b16(rk, int(k_off[r]), 0, 0));
+                    kx[g][r][1] = uint32_t(__builtin_amdgcn_raw_buffer_load_b16(rk, int(k_off[r] + 2u), 0, 0));
                 }
             }
         }
     };
+    auto reduce_group = [&](const int i0, const uint32_t (&em)[G][NR], const uint32_t (&ee)[G][NR], const uint32_t (&kx)[G][R][2], auto exact_tag) {
+        u16x2 vm[G][R], ve[G][R]; // V of this lane's pixel pair, of its extra pair, per row of the map: 3 · 4081 per half
+#pragma unroll
+        for(int g = 0; g < G; g++)
+#pragma unroll
+            for(int r = 0; r < R; r++)
+            {
+                vm[g][r] = as_u16x2(em[g][r]) + as_u16x2(em[g][r + 1]) + as_u16x2(em[g][r + 2]);
+                ve[g][r] = as_u16x2(ee[g][r]) + as_u16x2(ee[g][r + 1]) + as_u16x2(ee[g][r + 2]);
+            }
+        uint32_t t1m[G][R], t1e[G][R], t2m[G][R], t2e[G][R];
+#pragma unroll
+        for(int g = 0; g < G; g++)
+#pragma unroll
+            for(int r = 0; r < R; r++)
+            {
+                t1m[g][r] = uint32_t(__builtin_amdgcn_ds_bpermute(idx1, int(as_u32(vm[g][r]))));
+                t1e[g][r] = uint32_t(__builtin_amdgcn_ds_bpermute(idx1, int(as_u32(ve[g][r]))));
+                t2m[g][r] = uint32_t(__builtin_amdgcn_ds_bpermute(idx2, int(as_u32(vm[g][r]))));
+                t2e[g][r] = uint32_t(__builtin_amdgcn_ds_bpermute(idx2, int(as_u32(ve[g][r]))));
+            }
+#pragma unroll
+        for(int g = 0; g < G; g++)
+#pragma unroll
+            for(int r = 0; r < R; r++)
+            {
+                const int i = i0 + g;
+                const u16x2 acc = vm[g][r] + as_u16x2(own1 ? t1m[g][r] : t1e[g][r]) + as_u16x2(own2 ? t2m[g][r] : t2e[g][r]); // 9 · 4081 < 65536 per half
+                const uint32_t sum[2] = {as_u32(acc) & 0xffffu, as_u32(acc) >> 16};
+#pragma unroll
+                for(int j = 0; j < 2; j++)
+                {
+                    uint32_t key = sum[j] >= 16u ? (sum[j] & ~15u) : sum[j];
+                    if constexpr(decltype(exact_tag)::value)
+                        key = ((flagged[r][j] >> i) & 1u) ? (kx[g][r][j] & 0xffffu) : key;
+                    if(key < best_key[r][j]) // MinDispersion::add (src/kernels.cu:225-231): strict <
+                    {
+                        best_key[r][j] = key;
+                        best_i[r][j] = i;
+                    }
+                }
+            }
+    };
     auto all_candidates = [&](auto exact_tag) {
-        uint32_t em[G][3], ee[G][3], kx[G][2];
+        uint32_t em[G][NR], ee[G][NR], kx[G][R][2];
 #pragma unroll 1
         for(int i0 = 0; i0 < FOCUS_STEPS; i0 += G)
         {
@@ -1678,14 +1704,21 @@ __global__ void __launch_bounds__(64 * FPS_WAVES) focus_pick_sep(const KernelArg
     else
         all_candidates(std::false_type{});
 #pragma unroll
-    for(int j = 0; j < 2; j++)
-        if(x + j < W)
-        {
-            const float best_f = focus_candidate(a, best_i[j]);
-            const float normalized = __fdiv_rn(best_f - a.focus, a.range);
-            const uint32_t m = static_cast<uint32_t>(roundf(normalized * 255.0f)) & 0xffu;
-            reinterpret_cast<uint32_t *>(a.maps)[(size_t)y * W + x + j] = m | (m << 8) | (m << 16) | 0xff000000u;
-        }
+    for(int r = 0; r < R; r++)
+    {
+        const int y = y0 + r * rd;
+        if(y >= H) // wave-uniform
+            break;
+#pragma unroll
+        for(int j = 0; j < 2; j++)
+            if(x + j < W)
+            {
+                const float best_f = focus_candidate(a, best_i[r][j]);
+                const float normalized = __fdiv_rn(best_f - a.focus, a.range);
+                const uint32_t m = static_cast<uint32_t>(roundf(normalized * 255.0f)) & 0xffu;
+                reinterpret_cast<uint32_t *>(a.maps)[(size_t)y * W + x + j] = m | (m << 8) | (m << 16) | 0xff000000u;
+            }
+    }
 }
 
 } // namespace lfi

@@ -180,7 +180,7 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool di
     {
         const uint32_t groups = uint32_t(lfi::FOCUS_STEPS / range_cpw);
         const uint32_t ttx = uint32_t(w.We_p / lfi::FRT_TW), tty = uint32_t((w.He_p + lfi::FRT_TH - 1) / lfi::FRT_TH);
-        const int striped = ttx >= 8;
+        const int striped = ttx >= 8; // (row-major order of the items instead: range pass 1.64 → 1.71 ms at 4K)
         const uint32_t nblocks = striped ? 8u * lfi::stripe_blocks_per_xcd(ttx, tty, groups) : ttx * tty * groups;
         // persistent: one workgroup per CU (it owns the whole LDS), a multiple of 8 so that a workgroup's work items stay on its XCD
         const uint32_t grid = std::min(nblocks, uint32_t(std::max(ctx->cu_count / 8 * 8, 8)));
