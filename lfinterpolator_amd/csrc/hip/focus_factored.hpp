@@ -1294,12 +1294,15 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
             w.K[((size_t)i * H + y) * W + x] = static_cast<uint16_t>(encode(sum));
         }
     }
-    // (C)
-    constexpr int ROWS = 8;
-    const uint32_t row_blocks = uint32_t(H + ROWS - 1) / ROWS;
-    // A chunk of columns stays on ONE XCD (workgroups go round the XCDs: chunk c ↔ the workgroups ≡ c mod 8): a row of E under a chunk is
-    // sampled by three row blocks 2·ry apart — in one L2 the second and third find it, spread over eight they all go out to the fabric, for
-    // lines of which a chunk's columns use a fraction (150 → 130 µs at 4K; the flagged columns' taps touch most lines of E's 531 MB).
+    // (C)  a wave's unit = 64 flagged columns of a candidate (a lane each) × a COMB of CR rows ry apart: the tap rows of comb row k are comb rows
+    // k, k + 1, k + 2, so the three-tap sums H(q) = Σ_tx tap(x + tx·rx, q) of CR + 2 rows of E (or of the column's own lines) serve CR rows of keys
+    // — 3·(CR + 2) samples per lane instead of 9·CR, every row of E under a chunk read once (blocks of 8 adjacent rows left the re-use of a row,
+    // ry and 2·ry rows further down, to the L2: FETCH_SIZE 604 MB for ≈ 100 MB of lines, profiles/r05_notes.md §5).
+    constexpr int CR = 6;
+    const int rd = ry > 0 ? ry : 1;
+    const uint32_t combs = uint32_t((H + CR * rd - 1) / (CR * rd)) * uint32_t(rd); // bands of CR·ry rows, ry combs each
+    // A chunk of columns stays on ONE XCD (workgroups go round the XCDs: chunk c ↔ the workgroups ≡ c mod 8): the two chunks of a candidate's
+    // columns and the neighbouring combs share lines of E.
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t xcd_waves = (gridDim.x + 7u - xcd) / 8u * 4u, xcd_wave = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);
     const uint32_t my_chunks = (chunk_prefix[32] + 7u - xcd) / 8u;
@@ -1307,9 +1310,9 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
 #if defined(LK_SKIP) && (LK_SKIP & 2)
     if(false)
 #endif
-    for(uint32_t u = xcd_wave; u < my_chunks * row_blocks; u += xcd_waves)
+    for(uint32_t u = xcd_wave; u < my_chunks * combs; u += xcd_waves)
     {
-        const uint32_t chunk = xcd + 8u * (u / row_blocks), rb = u % row_blocks;
+        const uint32_t chunk = xcd + 8u * (u / combs), comb = u % combs;
         prefix_walk(chunk_prefix, chunk, ci);
         const int j = int(chunk - chunk_prefix[ci]) * 64 + lane;
         if(j >= ncols[ci])
@@ -1318,41 +1321,32 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
         const uint32_t cs = line_slot(w.colbase[x], w.badx[x], ci);
         if(cs >= uint32_t(w.C_cap))
             continue; // focus_exact (C)
-        bool own[3]; // per tap column (per lane): the column's own line, or the candidate's plane of E
-#pragma unroll
-        for(int tx = 0; tx < 3; tx++)
-            own[tx] = (w.tapx[(size_t)tx * W + x] >> ci) & 1u;
-        // Four rows at a time, all of their 36 samples in flight together (a row flagged for the candidate — focus_exact (A) — or below the image
-        // is sampled like the others, one row up at most, and not stored)
         const uint16_t *tap_base[3]; // per tap column (per lane): the column's own line, or the candidate's plane of E
         uint32_t tap_pitch[3];
 #pragma unroll
         for(int tx = 0; tx < 3; tx++)
         {
-            tap_base[tx] = own[tx] ? w.Ec + (size_t)tx * w.He_p * w.C_cap + cs : w.E + (size_t)ci * w.He_p * w.We_p + x + tx * rx;
-            tap_pitch[tx] = own[tx] ? uint32_t(w.C_cap) : uint32_t(w.We_p);
+            const bool own = (w.tapx[(size_t)tx * W + x] >> ci) & 1u;
+            tap_base[tx] = own ? w.Ec + (size_t)tx * w.He_p * w.C_cap + cs : w.E + (size_t)ci * w.He_p * w.We_p + x + tx * rx;
+            tap_pitch[tx] = own ? uint32_t(w.C_cap) : uint32_t(w.We_p);
+        }
+        const int band = int(comb) / rd, y0 = band * CR * rd + (int(comb) - band * rd); // wave-uniform
+        if(y0 >= H)
+            continue;
+        // all 3·(CR + 2) samples in flight together (rows below the extended image: the last one again, never used)
+        uint32_t hsum[CR + 2];
+#pragma unroll
+        for(int m = 0; m < CR + 2; m++)
+        {
+            const uint32_t q = uint32_t(min(y0 + m * ry, w.He_p - 1));
+            hsum[m] = uint32_t(tap_base[0][q * tap_pitch[0]]) + uint32_t(tap_base[1][q * tap_pitch[1]]) + uint32_t(tap_base[2][q * tap_pitch[2]]);
         }
 #pragma unroll
-        for(int y4 = 0; y4 < ROWS; y4 += 4)
+        for(int k = 0; k < CR; k++)
         {
-            const int yb = int(rb) * ROWS + y4;
-            if(yb >= H) // wave-uniform
-                break;
-            uint32_t sum[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for(int r = 0; r < 4; r++)
-            {
-                const uint32_t y = uint32_t(min(yb + r, H - 1));
-#pragma unroll
-                for(int tx = 0; tx < 3; tx++)
-#pragma unroll
-                    for(int ty = 0; ty < 3; ty++)
-                        sum[r] += tap_base[tx][(y + uint32_t(ty * ry)) * tap_pitch[tx]];
-            }
-#pragma unroll
-            for(int r = 0; r < 4; r++)
-                if(yb + r < H && !((w.bady[yb + r] >> ci) & 1u))
-                    w.K[((size_t)ci * H + yb + r) * W + x] = static_cast<uint16_t>(encode(sum[r]));
+            const int y = y0 + k * rd;
+            if(y < H && !((w.bady[y] >> ci) & 1u)) // (a row flagged for the candidate: focus_exact (A))
+                w.K[((size_t)ci * H + y) * W + x] = static_cast<uint16_t>(encode(hsum[k] + hsum[k + 1] + hsum[k + 2]));
         }
     }
     // (A') pairs flagged on both axes whose row and column both have a line slot: focus_exact left the corner taps' partial sum in K;
