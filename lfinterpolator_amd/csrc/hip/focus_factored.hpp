@@ -78,8 +78,24 @@ __device__ __forceinline__ float focus_candidate(const KernelArgs &a, int i)
     return __builtin_fmaf(step, static_cast<float>(i), a.focus);
 }
 
-// one thread per (candidate, view slot)
-__global__ void __launch_bounds__(1024) focus_plan_shifts(const KernelArgs a, const FocusWork w)
+struct FocusPatch;
+__device__ __forceinline__ void focus_plan_shift(const KernelArgs &a, const FocusWork &w);
+template <int CPW>
+__device__ __forceinline__ void focus_plan_patch(const KernelArgs &a, const FocusWork &w, FocusPatch *plans, int group, int k);
+
+// one thread per (candidate, view slot); then (cpw = 8 or 4) the first 32 / cpw · 32 threads plan focus_range_t's patches per (candidate group, view slot)
+__global__ void __launch_bounds__(1024) focus_plan_shifts(const KernelArgs a, const FocusWork w, FocusPatch *plans, const int cpw)
+{
+    focus_plan_shift(a, w);
+    __syncthreads(); // (one workgroup: its global stores are visible to its own threads behind the barrier)
+    const int i = threadIdx.x >> 5, k = threadIdx.x & 31;
+    if(cpw == 8 && i < FOCUS_STEPS / 8)
+        focus_plan_patch<8>(a, w, plans, i, k);
+    else if(cpw == 4 && i < FOCUS_STEPS / 4)
+        focus_plan_patch<4>(a, w, plans, i, k);
+}
+
+__device__ __forceinline__ void focus_plan_shift(const KernelArgs &a, const FocusWork &w)
 {
     const int i = threadIdx.x >> 5, k = threadIdx.x & 31;
     int32_t *dst = w.shifts + 4 * (i * FOCUS_MAX_IDS + k);
@@ -558,11 +574,10 @@ struct FocusPatch
     uint32_t unused[2];
 };
 
-// one thread per (group, view slot); after focus_plan_shifts
+// one thread per (group, view slot); behind focus_plan_shifts' barrier
 template <int CPW>
-__global__ void __launch_bounds__(32) focus_plan_patches(const KernelArgs a, const FocusWork w, FocusPatch *plans)
+__device__ __forceinline__ void focus_plan_patch(const KernelArgs &a, const FocusWork &w, FocusPatch *plans, const int group, const int k)
 {
-    const int group = blockIdx.x, k = threadIdx.x;
     if(k >= a.n_focus_ids)
         return;
     int sx[CPW], sy[CPW], ox = INT32_MAX, oy = INT32_MAX, mx = INT32_MIN, my = INT32_MIN;
@@ -588,6 +603,16 @@ __global__ void __launch_bounds__(32) focus_plan_patches(const KernelArgs a, con
 // its slots into the other half of the LDS while the reducing waves work on step s; ONE barrier per step.  Loading wave L: view L & 1 of the
 // step's pair, the row blocks ≡ L >> 1 (mod 2) of its patch (details at the loading branch below).
 constexpr int FRT_LW = 4; // loading waves
+// measurement builds (-DFRT_TRACE=1, tools/range_trace.sh): clocks per wave and category, read back by lfi_debug_frt_trace
+#ifndef FRT_TRACE
+#define FRT_TRACE 0
+#endif
+#if FRT_TRACE
+__device__ unsigned long long lfi_frt_trace_buf[256 * 16 * 8];
+#define FRT_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define FRT_T(var)
+#endif
 // At most 136 registers per lane (tests/test_abi_library.py checks the code object): three waves per SIMD then leave room for ONE wave of
 // focus_flagged (100 registers, no LDS) on every SIMD — the flagged passes run BESIDE this kernel on the side stream, as they ran beside focus_range; with
 // 3 × 168 registers taken they queued behind it and the focus map took as long as before (profiles/r05_notes.md).
@@ -672,7 +697,12 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
         // s are stored, so the texture path never idles while a wave waits for its last load and stores.
         u32x4 mA[MAIN_N], eA[EXTRA_N], mB[MAIN_N], eB[EXTRA_N];
         Geo gA{0, 0}, gB{0, 0};
+#if FRT_TRACE
+        unsigned long long tr_fetch = 0, tr_wait = 0, tr_store = 0, tr_bar = 0, tr_steps = 0;
+        int n_fetched = 0;
+#endif
         auto fetch = [&](const Step &st, u32x4 (&m)[MAIN_N], u32x4 (&e)[EXTRA_N], Geo &g) {
+            FRT_T(t0);
             const int kv = min(st.k + v, n_ids - 1); // an odd tail reduces the last view twice: no minimum or maximum changes
             const focus_const_u32_ptr pl = st.plan_words + kv * 8;
             const uint32_t src = pl[0] + st.tile_off;
@@ -688,10 +718,18 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
                 e[i] = u32x4{src, g.pr + i, g.pr, src};
             return;
 #endif
+#if FRT_TRACE
+            n_fetched = 0;
+#endif
 #pragma unroll
             for(int i = 0; i < MAIN_N; i++)
                 if(i < MAIN_SURE || uint32_t(4 * (2 * i + par)) < g.pr) // wave-uniform: the block's first row
+                {
                     m[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_main, int(src + uint32_t(4 * (2 * i + par)) * row_b), 0);
+#if FRT_TRACE
+                    n_fetched++;
+#endif
+                }
             if(g.sh)
             {
                 const int rows = 64 >> g.sh; // rows per block
@@ -699,8 +737,18 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
 #pragma unroll
                 for(int i = 0; i < EXTRA_N; i++)
                     if(uint32_t(rows * (2 * i + par)) < g.pr)
+                    {
                         e[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_extra, int(src + uint32_t(rows * (2 * i + par)) * row_b), 0);
+#if FRT_TRACE
+                        n_fetched++;
+#endif
+                    }
             }
+#if FRT_TRACE
+            asm volatile("" ::: "memory");
+            FRT_T(t1);
+            tr_fetch += t1 - t0;
+#endif
         };
         // A lane's four slots are 32 contiguous bytes, stored by two ds_write_b128.  The 8 lanes a 16-byte store serves together would hit every
         // bank twice if all of them stored their lower half first (23 % of all LDS cycles were conflicts), so the lanes with bit 2 set store their
@@ -720,8 +768,34 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
             *reinterpret_cast<u32x4 *>(dst + first_off) = s0;
             *reinterpret_cast<u32x4 *>(dst + (first_off ^ 16u)) = s1;
         };
-        auto store = [&](const u32x4 (&m)[MAIN_N], const u32x4 (&e)[EXTRA_N], const Geo &g) {
+        auto store = [&](const u32x4 (&m)[MAIN_N], const u32x4 (&e)[EXTRA_N], const Geo &g, const int younger) {
             // (every wave has passed the previous barrier: the reducing waves are done with this half, which held the step before the one they reduce now)
+#if FRT_TRACE
+            {
+                FRT_T(t0);
+                // wait for THIS set's loads (the other set's `younger` loads were issued after them)
+                switch(younger)
+                {
+                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+                }
+                FRT_T(t1);
+                tr_wait += t1 - t0;
+            }
+            FRT_T(ts0);
+#else
+            (void)younger;
+#endif
 #pragma unroll
             for(int i = 0; i < MAIN_N; i++)
                 if(i < MAIN_SURE || uint32_t(4 * (2 * i + par)) < g.pr)
@@ -736,36 +810,70 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
                     if(uint32_t(rows * (2 * i + par)) < g.pr && row0 + 2 * rows * i < FRT_PR_LDS) // (a block may reach below the rows of slots)
                         put(st_extra + 2 * rows * i * FRT_PW * 8, e[i]);
             }
+#if FRT_TRACE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            FRT_T(ts1);
+            tr_store += ts1 - ts0;
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's slots are in LDS
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#if FRT_TRACE
+            FRT_T(ts2);
+            tr_bar += ts2 - ts1;
+            tr_steps++;
+#endif
             half ^= 2u * FRT_VIEW_B;
         };
         Step sA = first_step_of(blockIdx.x);
         if(!sA.valid)
             return;
         fetch(sA, mA, eA, gA);
+        int young = 0; // (measurement builds) loads issued behind the set about to be stored
         for(;;)
         {
             const Step sB = next_step(sA);
+            young = 0;
             if(sB.valid)
+            {
                 fetch(sB, mB, eB, gB);
-            store(mA, eA, gA);
+#if FRT_TRACE
+                young = n_fetched;
+#endif
+            }
+            store(mA, eA, gA, young);
             if(!sB.valid)
                 break;
             sA = next_step(sB);
+            young = 0;
             if(sA.valid)
+            {
                 fetch(sA, mA, eA, gA);
-            store(mB, eB, gB);
+#if FRT_TRACE
+                young = n_fetched;
+#endif
+            }
+            store(mB, eB, gB, young);
             if(!sA.valid)
                 break;
         }
+#if FRT_TRACE
+        if(lane == 0 && blockIdx.x < 256)
+        {
+            unsigned long long *o = lfi_frt_trace_buf + (blockIdx.x * 16 + wave) * 8;
+            o[0] = tr_fetch, o[1] = tr_wait, o[2] = tr_store, o[3] = tr_bar, o[4] = tr_steps;
+        }
+#endif
         return;
     }
     // ---- a reducing wave: rows 4·wave … 4·wave + 3 of the tile, column lane
     // LDS address of this lane's column in the first of its four rows
     constexpr int PAIRS = FRT_RPW / 2; // row pairs per reducing lane
     const uint32_t rd_addr = uint32_t(uintptr_t((__attribute__((address_space(3))) void *)lds)) + uint32_t(FRT_RPW * wave * FRT_PW + lane) * 8u;
+#if FRT_TRACE
+    unsigned long long rr_bar = 0, rr_red = 0, rr_epi = 0, rr_steps = 0;
+    const unsigned long long rr_begin = __builtin_amdgcn_s_memtime();
+#endif
     for(uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x)
     {
     uint32_t tx, ty, group;
@@ -793,9 +901,11 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
             for(int q = 0; q < 4; q++)
                 dc[v][q] = pl[2 + q];
         }
+        FRT_T(tb0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the plan words; the previous step's reads were consumed)
         __builtin_amdgcn_s_barrier();                       // step k's slots are in LDS
         asm volatile("" ::: "memory");
+        FRT_T(tb1);
         // The reduction.  LDS reads by inline assembly: every slot is read whole (ds_read_b64) although of the second row of a pair only
         // [R,G] is used — the compiler narrows such a read to ds_read_b32, and 4-byte reads at an 8-byte lane stride run into two-way bank
         // conflicts (25 % of all LDS cycles, profiles/r05_pmc_range_t_first.txt).  Unit of the pipeline = one ROW PAIR of one candidate: four
@@ -866,9 +976,15 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
                 issue_unit(u + D - 1);
             reduce(u / PAIRS, u % PAIRS, q[u % D], (UNITS - 1 - u) < (D - 1) ? (UNITS - 1 - u) : (D - 1));
         }
+#if FRT_TRACE
+        asm volatile("" ::: "memory");
+        FRT_T(tb2);
+        rr_bar += tb1 - tb0, rr_red += tb2 - tb1, rr_steps++;
+#endif
         half ^= 2u * FRT_VIEW_B;
     }
     // E: 16·range + (FLT_MIN tap ? 1 : 0) per pixel (focus_map.hpp); a lane holds rows 4·wave … 4·wave + 3 of its column
+    FRT_T(te0);
     const int ey0 = int(ty) * FRT_TH + FRT_RPW * wave;
     const uint32_t ex = tx * FRT_TW + lane;
 #pragma unroll
@@ -892,7 +1008,19 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
             if(ey + 1 < w.He_p)
                 dst[w.We_p] = static_cast<uint16_t>(enc >> 16);
         }
+#if FRT_TRACE
+    asm volatile("" ::: "memory");
+    FRT_T(te1);
+    rr_epi += te1 - te0;
+#endif
     } // work items
+#if FRT_TRACE
+    if(lane == 0 && blockIdx.x < 256)
+    {
+        unsigned long long *o = lfi_frt_trace_buf + (blockIdx.x * 16 + wave) * 8;
+        o[0] = rr_bar, o[1] = rr_red, o[2] = rr_epi, o[3] = __builtin_amdgcn_s_memtime() - rr_begin, o[4] = rr_steps;
+    }
+#endif
 }
 
 // 64-bit readlane (lane index uniform)

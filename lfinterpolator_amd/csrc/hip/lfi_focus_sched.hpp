@@ -151,17 +151,19 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool di
     hipStream_t st = ctx->stream;
     hipStream_t aux = ctx->aux_stream;
     // host launch order = the critical path first: the main stream's kernels are enqueued before the side stream's
-    hipLaunchKernelGGL(lfi::focus_plan_shifts, dim3(1), dim3(1024), 0, st, a, w);
-    if(range_cpw == 8)
-        hipLaunchKernelGGL(lfi::focus_plan_patches<8>, dim3(lfi::FOCUS_STEPS / 8), dim3(32), 0, st, a, w, patches);
-    else if(range_cpw == 4)
-        hipLaunchKernelGGL(lfi::focus_plan_patches<4>, dim3(lfi::FOCUS_STEPS / 4), dim3(32), 0, st, a, w, patches);
+    // (the patch plans of focus_range_t by the same launch: one kernel less in front of the range pass)
+    hipLaunchKernelGGL(lfi::focus_plan_shifts, dim3(1), dim3(1024), 0, st, a, w, patches, range_cpw);
     LFI_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+    bool padded_any = true; // something was enqueued between ev_fork and the range pass
     if(pad_kept && ctx->pad_version != 0) // (a reallocated workspace cleared pad_version)
     {
+        padded_any = false;
         for(int k = 0; k < ctx->n_focus_ids; k++)
             if(image_changed_since(ctx, ctx->h_focus_ids[k], ctx->pad_version))
+            {
                 hipLaunchKernelGGL(lfi::focus_pad, dim3((w.Wp + 255) / 256, (w.Hp + lfi::FOCUS_PAD_ROWS - 1) / lfi::FOCUS_PAD_ROWS, 1), dim3(64), 0, st, a, w, k);
+                padded_any = true;
+            }
         ctx->pad_version = ctx->grid_version;
     }
     else
@@ -174,7 +176,9 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool di
         ctx->pad_radius[1] = ry;
         ctx->pad_ids = ctx->h_focus_ids;
     }
-    LFI_HIP(ctx, hipEventRecord(ctx->ev_pad, st));
+    // (planes kept and nothing re-padded: ev_fork says all the side stream needs to know — one event packet less in front of the range pass)
+    if(padded_any)
+        LFI_HIP(ctx, hipEventRecord(ctx->ev_pad, st));
     const uint32_t tiles_x = uint32_t(w.We_p / 256), tiles_y = uint32_t(w.He_p / 4);
     if(range_cpw)
     {
@@ -201,7 +205,8 @@ int launch_focus_factored(lfi_ctx *ctx, const KernelArgs &a, bool *done, bool di
     hipLaunchKernelGGL(lfi::focus_plan_flags, dim3((std::max(W, H) + 255) / 256, lfi::FOCUS_STEPS, 2), dim3(256), 0, aux, a, w);
     hipLaunchKernelGGL(lfi::focus_plan_lists, dim3(lfi::FOCUS_STEPS, 2), dim3(64), 0, aux, a, w);
     hipLaunchKernelGGL(lfi::focus_plan_prefix, dim3(1), dim3(1), 0, aux, a, w);
-    LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_pad, 0));
+    if(padded_any)
+        LFI_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_pad, 0));
     {
         const uint32_t per_pass = uint32_t(ctx->cu_count) * 4u / 8u * 8u;
 #ifdef LFI_MEASUREMENT_BUILD // one launch per pass, so that a kernel trace shows what each of the three costs

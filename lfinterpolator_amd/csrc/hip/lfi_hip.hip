@@ -1527,6 +1527,13 @@ int lfi_debug_sx_trace(unsigned long long *out, int n_words)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(lfi::lfi_sx_trace_buf), sizeof(unsigned long long) * std::min(n_words, 1024 * 32)) == hipSuccess ? 0 : 1;
 }
 #endif
+#if FRT_TRACE
+// measurement builds only (focus_factored.hpp): clocks per wave and category of the last focus_range_t launch; not part of include/lfi.h
+int lfi_debug_frt_trace(unsigned long long *out, int n_words)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(lfi::lfi_frt_trace_buf), sizeof(unsigned long long) * std::min(n_words, 256 * 16 * 8)) == hipSuccess ? 0 : 1;
+}
+#endif
 #if LFI_P3_TRACE
 // measurement builds only (blend_p3.hpp): the per-workgroup unit clocks of the last blend_p3 launch; not part of include/lfi.h
 int lfi_debug_p3_trace(unsigned long long *out, int n_words)
