@@ -648,6 +648,10 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
         // their rate).  "main": 64 columns × blocks of 4 rows (lane & 15 = quad of pixels, lane >> 4 = row); "extra": the 32 columns behind
         // them × blocks of 8 rows (lane & 7 = quad, lane >> 3 = row; all 32 columns whatever the patch's width — columns beyond it land
         // in slots nobody reads, as do rows beyond its height: FRT_PR_LDS rows of slots exist).
+        // (tools/range_trace.py, clocks per step at 4K: a loading wave spends 500-570 issuing its fetch, 220-240 waiting for the loads, 1,450-1,520
+        // widening and storing and 570 at the barrier; a reducing wave 1,380 reducing, 240 on its share of the epilogue and 1,320 at the barrier:
+        // the loading side is the step's critical path, and its stores queue behind the reducing waves' reads in the LDS.  Raising the loading
+        // waves' priority (s_setprio 3) changes nothing: 1,630 against 1,610 µs.)
         const int lw = wave - FRT_NW, v = lw & 1, par = lw >> 1;
         const uint32_t row_b = uint32_t(w.Wp) * 4u;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(w.pad, 0, int(pad_bytes), 0x00020000);
@@ -986,7 +990,6 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
     // E: 16·range + (FLT_MIN tap ? 1 : 0) per pixel (focus_map.hpp); a lane holds rows 4·wave … 4·wave + 3 of its column
     FRT_T(te0);
     const int ey0 = int(ty) * FRT_TH + FRT_RPW * wave;
-    const uint32_t ex = tx * FRT_TW + lane;
 #pragma unroll
     for(int c = 0; c < CPW; c++)
 #pragma unroll
@@ -1002,11 +1005,13 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
             const u16x2 nz = __builtin_elementwise_min(as_u16x2(as_u32(dmax) | as_u32(hmin)), as_u16x2(0x00010001u));
             const uint32_t enc = (as_u32(dmax) << 4) + (0x00010001u - as_u32(nz)); // per half: 16·range ≤ 4080, no carry
             const int ey = ey0 + 2 * u;
-            uint16_t *dst = w.E + ((size_t)(group * CPW + c) * w.He_p + ey) * w.We_p + ex;
+            // One dword store per lane instead of two 16-bit ones: neighbouring lanes swap — the even lane stores both columns' values of
+            // row ey, the odd lane both of row ey + 1 (ey is even and He_p a multiple of 4: both rows exist or neither).
+            const uint32_t other = uint32_t(__builtin_amdgcn_mov_dpp(int(enc), 0xB1, 0xf, 0xf, false)); // quad_perm [1, 0, 3, 2]
+            const uint32_t both = __builtin_amdgcn_perm(other, enc, (lane & 1) ? 0x03020706u : 0x05040100u);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(w.E + ((size_t)(group * CPW + c) * w.He_p + ey) * w.We_p + (tx * FRT_TW + (lane & ~1)) + ((lane & 1) ? w.We_p : 0));
             if(ey < w.He_p) // wave-uniform: the last tile row of an image whose extended height is not a multiple of the tile's
-                dst[0] = static_cast<uint16_t>(enc);
-            if(ey + 1 < w.He_p)
-                dst[w.We_p] = static_cast<uint16_t>(enc >> 16);
+                *dst = both;
         }
 #if FRT_TRACE
     asm volatile("" ::: "memory");
