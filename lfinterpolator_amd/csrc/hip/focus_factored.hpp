@@ -558,7 +558,10 @@ __global__ void __launch_bounds__(256) focus_range(const KernelArgs a, const Foc
 #define FRT_DEPTH 2 // units (four LDS reads each) a reducing wave keeps in flight
 #endif
 constexpr int FRT_TW = 64;                          // tile: extended columns (one per lane); rows: FRT_RPW per reducing wave
-constexpr int FRT_NW = FRT_RPW == 4 ? 8 : 12, FRT_TH = FRT_RPW * FRT_NW; // reducing waves per workgroup, tile rows
+#ifndef FRT_LWAVES
+#define FRT_LWAVES 4 // loading waves: 4 (beside eight reducing waves, tile 64 × 32) or 6 (beside six, tile 64 × 24)
+#endif
+constexpr int FRT_NW = FRT_RPW == 4 ? 12 - FRT_LWAVES : 12, FRT_TH = FRT_RPW * FRT_NW; // reducing waves per workgroup, tile rows
 constexpr int FRT_MAX_DX = 32, FRT_MAX_DY = 18;     // the largest span of a view's shifts within a candidate group
 constexpr int FRT_PW = FRT_TW + FRT_MAX_DX;         // a view's patch in LDS: pixels per row (the row pitch) …
 constexpr int FRT_PR = FRT_TH + FRT_MAX_DY;         // … × rows, at most
@@ -602,7 +605,7 @@ __device__ __forceinline__ void focus_plan_patch(const KernelArgs &a, const Focu
 // three phases added up: profiles/r05_notes.md).  So the roles are split: the loading waves fetch step s + 1's patches, widen them and store
 // its slots into the other half of the LDS while the reducing waves work on step s; ONE barrier per step.  Loading wave L: view L & 1 of the
 // step's pair, the row blocks ≡ L >> 1 (mod 2) of its patch (details at the loading branch below).
-constexpr int FRT_LW = 4; // loading waves
+constexpr int FRT_LW = FRT_LWAVES; // loading waves: view L & 1 of a step's pair, the row blocks ≡ L >> 1 (mod FRT_LW / 2) of its patch
 // measurement builds (-DFRT_TRACE=1, tools/range_trace.sh): clocks per wave and category, read back by lfi_debug_frt_trace
 #ifndef FRT_TRACE
 #define FRT_TRACE 0
@@ -652,12 +655,13 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
         // widening and storing and 570 at the barrier; a reducing wave 1,380 reducing, 240 on its share of the epilogue and 1,320 at the barrier:
         // the loading side is the step's critical path, and its stores queue behind the reducing waves' reads in the LDS.  Raising the loading
         // waves' priority (s_setprio 3) changes nothing: 1,630 against 1,610 µs.)
+        constexpr int NP = FRT_LW / 2; // loading waves per view
         const int lw = wave - FRT_NW, v = lw & 1, par = lw >> 1;
         const uint32_t row_b = uint32_t(w.Wp) * 4u;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(w.pad, 0, int(pad_bytes), 0x00020000);
         const int v_main = (lane >> 4) * int(row_b) + (lane & 15) * 16;
-        constexpr int MAIN_N = ((FRT_PR + 3) / 4 + 1) / 2, EXTRA_N = ((FRT_PR + 7) / 8 + 1) / 2; // row blocks of one parity
-        constexpr int MAIN_SURE = FRT_TH / 8;                                                     // … that every patch has
+        constexpr int MAIN_N = ((FRT_PR + 3) / 4 + NP - 1) / NP, EXTRA_N = ((FRT_PR + 7) / 8 + NP - 1) / NP; // row blocks of one wave
+        constexpr int MAIN_SURE = FRT_TH / (4 * NP);                                                        // … that every patch has
         uint8_t *const st_main = lds + v * FRT_VIEW_B + ((4 * par + (lane >> 4)) * FRT_PW + 4 * (lane & 15)) * 8;
         // The "extra" part is as wide as the patch needs it — 2, 4 or 8 quads of pixels, i.e. blocks of 32, 16 or 8 rows per wave-load (most
         // views' shifts span few columns: a third of all stored slots lay beyond their patches with a fixed width of 8 quads)
@@ -727,9 +731,9 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
 #endif
 #pragma unroll
             for(int i = 0; i < MAIN_N; i++)
-                if(i < MAIN_SURE || uint32_t(4 * (2 * i + par)) < g.pr) // wave-uniform: the block's first row
+                if(i < MAIN_SURE || uint32_t(4 * (NP * i + par)) < g.pr) // wave-uniform: the block's first row
                 {
-                    m[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_main, int(src + uint32_t(4 * (2 * i + par)) * row_b), 0);
+                    m[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_main, int(src + uint32_t(4 * (NP * i + par)) * row_b), 0);
 #if FRT_TRACE
                     n_fetched++;
 #endif
@@ -740,9 +744,9 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
                 const int v_extra = (lane >> g.sh) * int(row_b) + 4 * FRT_TW + (lane & ((1 << g.sh) - 1)) * 16;
 #pragma unroll
                 for(int i = 0; i < EXTRA_N; i++)
-                    if(uint32_t(rows * (2 * i + par)) < g.pr)
+                    if(uint32_t(rows * (NP * i + par)) < g.pr)
                     {
-                        e[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_extra, int(src + uint32_t(rows * (2 * i + par)) * row_b), 0);
+                        e[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v_extra, int(src + uint32_t(rows * (NP * i + par)) * row_b), 0);
 #if FRT_TRACE
                         n_fetched++;
 #endif
@@ -802,8 +806,8 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
 #endif
 #pragma unroll
             for(int i = 0; i < MAIN_N; i++)
-                if(i < MAIN_SURE || uint32_t(4 * (2 * i + par)) < g.pr)
-                    put(st_main + half + 8 * i * FRT_PW * 8, m[i]);
+                if(i < MAIN_SURE || uint32_t(4 * (NP * i + par)) < g.pr)
+                    put(st_main + half + 4 * NP * i * FRT_PW * 8, m[i]);
             if(g.sh)
             {
                 const int rows = 64 >> g.sh;
@@ -811,8 +815,8 @@ __global__ void __launch_bounds__(64 * (FRT_NW + FRT_LW), 1) focus_range_t(const
                 uint8_t *const st_extra = lds + v * FRT_VIEW_B + half + (row0 * FRT_PW + FRT_TW + 4 * (lane & ((1 << g.sh) - 1))) * 8;
 #pragma unroll
                 for(int i = 0; i < EXTRA_N; i++)
-                    if(uint32_t(rows * (2 * i + par)) < g.pr && row0 + 2 * rows * i < FRT_PR_LDS) // (a block may reach below the rows of slots)
-                        put(st_extra + 2 * rows * i * FRT_PW * 8, e[i]);
+                    if(uint32_t(rows * (NP * i + par)) < g.pr && row0 + NP * rows * i < FRT_PR_LDS) // (a block may reach below the rows of slots)
+                        put(st_extra + NP * rows * i * FRT_PW * 8, e[i]);
             }
 #if FRT_TRACE
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -1,6 +1,6 @@
 """Where focus_range_t's waves spend their clocks (measurement build -DFRT_TRACE=1, LFI_AB_LIB selects it): per loading wave the fetch issue, the
 wait for its loads, widen + LDS stores, the barrier; per reducing wave the barrier, the reduction, the epilogue.  usage: LFI_AB_LIB=… python tools/range_trace.py"""
-import sys, ctypes
+import os, sys, ctypes
 sys.path.insert(0, "."); sys.path.insert(0, "tools")
 import numpy as np
 import lfinterpolator_amd as L
@@ -15,13 +15,14 @@ lib = ctypes.CDLL(abi.HIP_LIB)
 buf = np.zeros(256 * 16 * 8, np.uint64)
 assert lib.lfi_debug_frt_trace(buf.ctypes.data_as(ctypes.c_void_p), buf.size) == 0
 t = buf.reshape(256, 16, 8).astype(np.float64)
-red, ld = t[:, :8], t[:, 8:12]
+NRED = int(os.environ.get("FRT_NRED", "8"))  # reducing waves of the build (12 - FRT_LWAVES)
+red, ld = t[:, :NRED], t[:, NRED:12]
 steps = red[:, :, 4].mean()
 print(f"steps per workgroup {steps:.0f}; clocks per step (mean over 256 workgroups and the role's waves)")
 print(f"  reducing waves: barrier wait {red[:, :, 0].mean() / steps:7.0f}  reduction {red[:, :, 1].mean() / steps:7.0f}  epilogue {red[:, :, 2].mean() / steps:7.0f}  | whole kernel {red[:, :, 3].mean() / steps:7.0f}")
 print(f"  loading waves : fetch issue  {ld[:, :, 0].mean() / steps:7.0f}  wait for loads {ld[:, :, 1].mean() / steps:7.0f}  widen + LDS stores {ld[:, :, 2].mean() / steps:7.0f}  barrier {ld[:, :, 3].mean() / steps:7.0f}")
-for wv in range(4):
+for wv in range(12 - NRED):
     print(f"    loader {wv}: fetch {ld[:, wv, 0].mean() / steps:6.0f} wait {ld[:, wv, 1].mean() / steps:6.0f} store {ld[:, wv, 2].mean() / steps:6.0f} barrier {ld[:, wv, 3].mean() / steps:6.0f}")
-print("  reducing waves' barrier wait by wave:", " ".join(f"{red[:, wv, 0].mean() / steps:.0f}" for wv in range(8)))
-print("  reducing waves' reduction by wave:   ", " ".join(f"{red[:, wv, 1].mean() / steps:.0f}" for wv in range(8)))
+print("  reducing waves' barrier wait by wave:", " ".join(f"{red[:, wv, 0].mean() / steps:.0f}" for wv in range(NRED)))
+print("  reducing waves' reduction by wave:   ", " ".join(f"{red[:, wv, 1].mean() / steps:.0f}" for wv in range(NRED)))
 ctx.close()
