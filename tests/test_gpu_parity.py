@@ -551,6 +551,37 @@ def test_focus_map_edge_shapes_both_range_passes(case, gpu, oracle_c):
     ctx.close()
 
 
+@pytest.mark.parametrize("case", [(129, 50, (2, 1)), (257, 70, (64, 3)), (300, 70, (66, 2)), (640, 200, (8, 6)), (1000, 33, (38, 22)), (130, 40, (40, 30)),
+                                  (256, 97, (4, 1)), (2050, 48, (20, 2))],
+                         ids=lambda c: "%dx%d_r%dx%d" % (c[0], c[1], c[2][0], c[2][1]))
+def test_focus_map_pick_and_keys_at_their_dispatch_edges(case, gpu, oracle_c):
+    """focus_pick_sep (round 5: the tap block taken apart, sixteen waves on rows radius_y apart, two rows of the map per wave) and the comb form
+    of focus_line_keys' column part at the edges of their geometry: widths one past a multiple of 128, radius_x of 2 (one lane of extra columns),
+    64 (the last radius the kernel takes: taps two whole waves further on) and 66 (focus_pick<2> instead), radius_y of 1 (a band of 32 rows) and
+    above the image's height (one band, most waves idle; combs with a single row), heights that end inside a band.  Quantised inputs with a black
+    region (ties, FLT_MIN taps), a corner where rows AND columns are flagged; `factored` and `factored_direct` (the other pick), maps 0 and 1."""
+    W, H, rad = case
+    cols, rows = 6, 5
+    hp = gpu.build_params(cols, rows, W, H, "0.071,0.071,0.93,0.93", 0.22, 0.3, 7.0, 1.783, 2)
+    hp.block_radius = np.array(rad, np.int32)
+    lf = oracle_c.synthetic_lf(cols * rows, W, H, 77 + W + rad[0])
+    lf = (lf // 16 * 16).astype(np.uint8)
+    lf[:, : H // 3, W // 2 :, :3] = 0
+    lf[..., 3] = 255
+    want0 = oracle_c.focus_estimate(lf, hp.offsets, hp.focus_map_ids, hp.focus, hp.range, hp.block_radius, threads=8)
+    want1 = oracle_c.focus_filter(want0, hp.block_radius)
+    assert len(np.unique(want0[..., 0])) > 2
+    ctx = _ctx(gpu, cols, rows, W, H, hp, lf=lf)
+    for variant in ("factored", "factored_direct"):
+        ctx.set_variant("FOCUS", variant)
+        ctx.focus_map()
+        ctx.sync()
+        got0 = ctx.download_map(0)
+        assert (got0 == want0).all(), (variant, int((got0 != want0).any(-1).sum()))
+        assert (ctx.download_map(1) == want1).all(), variant
+    ctx.close()
+
+
 def test_focus_map_padded_planes_are_kept_between_calls(gpu, oracle_c):
     """lfi_focus_map keeps the padded copies of the sampled images while the inputs are unchanged (a focus sweep over one light field pads
     once).  Every call must still give the oracle's bytes: the same parameters again (planes reused), a smaller and a larger focus
