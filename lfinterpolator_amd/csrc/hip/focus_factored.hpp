@@ -1689,11 +1689,12 @@ __global__ void __launch_bounds__(64 * FPS_WAVES) focus_pick_sep(const KernelArg
     const int x0 = int(bx) * 128, x = x0 + 2 * lane;
     const int rx = a.radius_x, ry = a.radius_y;
     // A workgroup's waves and a wave's R rows are ry APART (row j of a band of 16·R·ry rows, then j + ry, j + 2·ry, …): the tap rows of a row
-    // are its own and the next two of that sequence, so a wave loads R + 2 rows of E for R rows of the map and a workgroup reads 16·R + 2 rows
-    // for 16·R — from the fabric once; the uses by the neighbouring waves are hits on its own CU at about the same time.  Workgroups in
-    // row-major order.  (Four ADJACENT rows per workgroup in stripes per XCD, focus_pick<2>'s mapping, leave the re-use of a row of E — ry and
-    // 2·ry rows further down the stripe — to the XCD's L2: FETCH_SIZE 880 MB for E's 531 MB, 267 µs at 4K whatever the kernel did per wave;
-    // 16 / 8 / 4 waves of one row each, ry apart: 238 / 253 / 272 µs — profiles/r05_focus_pick_experiments.txt.)
+    // are its own and the next two of that sequence, so a wave loads R + 2 rows of E for R rows of the map and the uses of a row of E by the
+    // neighbouring waves fall on one CU at about the same time.  Workgroups in row-major order.  MEASURED, not derived (profiles/
+    // r05_focus_pick_experiments.txt): four ADJACENT rows per workgroup in stripes per XCD (focus_pick<2>'s mapping) took 267 µs at 4K whatever the
+    // kernel did per wave — loads per candidate, registers, occupancy, E's layout, HALF the bytes per sample — and longer the more rows a stripe had
+    // in flight; 16 / 8 / 4 waves of one row each, ry apart, row-major: 238 / 253 / 272 µs; two rows per wave: 218.  (Not by fewer bytes from the
+    // fabric: FETCH_SIZE × 2 is 1.3 GB for this mapping against 0.88 GB for the stripes.)
     const int rd = ry > 0 ? ry : 1;
     const int band = int(by) / rd, j0 = int(by) - band * rd;
     const int y0 = __builtin_amdgcn_readfirstlane(((band * FPS_WAVES + int(threadIdx.x >> 6)) * R) * rd + j0);
@@ -1760,8 +1761,13 @@ __global__ void __launch_bounds__(64 * FPS_WAVES) focus_pick_sep(const KernelArg
 #pragma unroll
             for(int q = 0; q < NR; q++)
             {
+#ifdef FPS_HALF // measurement builds: half the bytes per sample (what an 8-bit E would move; the maps are wrong)
+                em[g][q] = uint32_t(__builtin_amdgcn_raw_buffer_load_b16(re, int(main_off[q] >> 1), 0, 0));
+                ee[g][q] = uint32_t(__builtin_amdgcn_raw_buffer_load_b16(re, int(extra_off[q] == 0xfffffff0u ? extra_off[q] : extra_off[q] >> 1), 0, 0));
+#else
                 em[g][q] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(re, int(main_off[q]), 0, 0));
                 ee[g][q] = uint32_t(__builtin_amdgcn_raw_buffer_load_b32(re, int(extra_off[q]), 0, 0));
+#endif
             }
             if constexpr(decltype(exact_tag)::value)
             {
