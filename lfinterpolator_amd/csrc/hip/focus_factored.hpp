@@ -1748,10 +1748,15 @@ __global__ void __launch_bounds__(64 * FPS_WAVES) focus_pick_sep(const KernelArg
 #pragma unroll
     for(int r = 0; r < R; r++)
         best_key[r][0] = best_key[r][1] = 0xffffffffu, best_i[r][0] = best_i[r][1] = 0;
-    // Candidates in groups of four: a group's loads of E (and its keys of K) are issued together, then summed.  (One row per wave: one to sixteen
-    // candidates per group, one or two groups in flight, 40 to 154 registers, three to eight workgroups per CU all took the same time.)
-    constexpr int G = 4;
-    static_assert(FOCUS_STEPS % G == 0, "whole groups");
+    // Candidates in groups of two: a group's loads of E (and its keys of K) are issued together, then summed.
+#ifndef FPS_G
+#define FPS_G 2 // (measurement builds: 1 / 2 / 4 / 8 candidates per group → 212 / 208 / 217 / 241 µs at 4K; two groups in flight, -DFPS_DB=1: 212 (G = 1), 237 (G = 2))
+#endif
+#ifndef FPS_DB
+#define FPS_DB 0
+#endif
+    constexpr int G = FPS_G;
+    static_assert(FOCUS_STEPS % (G * (1 + FPS_DB)) == 0, "whole groups");
     auto load_group = [&](const int i0, uint32_t (&em)[G][NR], uint32_t (&ee)[G][NR], uint32_t (&kx)[G][R][2], auto exact_tag) {
 #pragma unroll
         for(int g = 0; g < G; g++)
@@ -1827,6 +1832,24 @@ __global__ void __launch_bounds__(64 * FPS_WAVES) focus_pick_sep(const KernelArg
     };
     auto all_candidates = [&](auto exact_tag) {
         uint32_t em[G][NR], ee[G][NR], kx[G][R][2];
+#if FPS_DB // measurement builds: two groups in flight
+        uint32_t emB[G][NR], eeB[G][NR], kxB[G][R][2];
+        load_group(0, em, ee, kx, exact_tag);
+#pragma unroll 1
+        for(int i0 = 0; i0 < FOCUS_STEPS; i0 += 2 * G)
+        {
+            load_group(i0 + G, emB, eeB, kxB, exact_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            reduce_group(i0, em, ee, kx, exact_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            if(i0 + 2 * G < FOCUS_STEPS)
+                load_group(i0 + 2 * G, em, ee, kx, exact_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            reduce_group(i0 + G, emB, eeB, kxB, exact_tag);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+#endif
 #pragma unroll 1
         for(int i0 = 0; i0 < FOCUS_STEPS; i0 += G)
         {
