@@ -1667,11 +1667,15 @@ __global__ void __launch_bounds__(256) focus_pick(const KernelArgs a, const Focu
 // instead of 9 full ones.  focus_pick<2> runs at the L1's tag rate (4-byte loads at 4-byte alignment: 5.6 tag accesses per load, the L1 busy
 // 64 % of the kernel); the sums are the same integers in any order, so the map is bit-identical.  Needs an even radius_x ≤ 64 (the reference's
 // is even, src/interpolator.cu:143-146; 64 ↔ images up to 6,400 pixels wide) — else focus_pick<PPL>.  Same block → pixel mapping (stripes per XCD).
-constexpr int FPS_WAVES = 16; // waves per workgroup of focus_pick_sep
-#ifndef FPS_R
-#define FPS_R 2 // (measurement builds: 1 … 4)
+#ifndef FPS_NW
+#define FPS_NW 4 // (measurement builds: 2 … 16)
 #endif
-constexpr int FPS_ROWS = FPS_R; // rows of the map per wave (radius_y apart): 1 / 2 / 3 / 4 → 239 / 218 / 237 / 233 µs at 4K
+constexpr int FPS_WAVES = FPS_NW; // waves per workgroup of focus_pick_sep
+#ifndef FPS_R
+#define FPS_R 4 // (measurement builds: 1 … 8)
+#endif
+constexpr int FPS_ROWS = FPS_R; // rows of the map per wave (radius_y apart).  Waves × rows at 4K (profiles/r05_focus_pick_experiments.txt): 16 × 1 / 2 / 3 / 4 →
+                                // 239 / 218 (208 with candidates in groups of two) / 237 / 233 µs; 8 × 4 → 199; 4 × 4 → 199 (the product); 4 × 6 → 202; 4 × 8 → 213; 2 × 8 → 207
 // rows of workgroups of focus_pick_sep: bands of FPS_WAVES·FPS_ROWS·ry rows of the map, ry workgroups each
 __host__ __device__ __forceinline__ uint32_t focus_pick_sep_block_rows(const int H, const int ry)
 {
@@ -1688,13 +1692,13 @@ __global__ void __launch_bounds__(64 * FPS_WAVES) focus_pick_sep(const KernelArg
     const int lane = int(threadIdx.x & 63);
     const int x0 = int(bx) * 128, x = x0 + 2 * lane;
     const int rx = a.radius_x, ry = a.radius_y;
-    // A workgroup's waves and a wave's R rows are ry APART (row j of a band of 16·R·ry rows, then j + ry, j + 2·ry, …): the tap rows of a row
-    // are its own and the next two of that sequence, so a wave loads R + 2 rows of E for R rows of the map and the uses of a row of E by the
-    // neighbouring waves fall on one CU at about the same time.  Workgroups in row-major order.  MEASURED, not derived (profiles/
+    // A workgroup's waves and a wave's R rows are ry APART (row j of a band of NW·R·ry rows, then j + ry, j + 2·ry, …): the tap rows of a row are
+    // its own and the next two of that sequence, so a wave loads R + 2 rows of E for R rows of the map (in registers) and the uses of a row of E
+    // by the neighbouring waves fall on one CU at about the same time.  Workgroups in row-major order.  MEASURED, not derived (profiles/
     // r05_focus_pick_experiments.txt): four ADJACENT rows per workgroup in stripes per XCD (focus_pick<2>'s mapping) took 267 µs at 4K whatever the
     // kernel did per wave — loads per candidate, registers, occupancy, E's layout, HALF the bytes per sample — and longer the more rows a stripe had
-    // in flight; 16 / 8 / 4 waves of one row each, ry apart, row-major: 238 / 253 / 272 µs; two rows per wave: 218.  (Not by fewer bytes from the
-    // fabric: FETCH_SIZE × 2 is 1.3 GB for this mapping against 0.88 GB for the stripes.)
+    // in flight; 16 / 8 / 4 waves of one row each, ry apart, row-major: 238 / 253 / 272 µs; 16 waves of two rows: 208-218; four waves of four: 199.
+    // (Not by fewer bytes from the fabric: FETCH_SIZE × 2 was 1.3 GB for 16 × 2 rows against 0.88 GB for the stripes.)
     const int rd = ry > 0 ? ry : 1;
     const int band = int(by) / rd, j0 = int(by) - band * rd;
     const int y0 = __builtin_amdgcn_readfirstlane(((band * FPS_WAVES + int(threadIdx.x >> 6)) * R) * rd + j0);
