@@ -1435,21 +1435,18 @@ __global__ void __launch_bounds__(256) focus_line_keys(const KernelArgs a, const
     // k, k + 1, k + 2, so the three-tap sums H(q) = Σ_tx tap(x + tx·rx, q) of CR + 2 rows of E (or of the column's own lines) serve CR rows of keys
     // — 3·(CR + 2) samples per lane instead of 9·CR, every row of E under a chunk read once (blocks of 8 adjacent rows left the re-use of a row,
     // ry and 2·ry rows further down, to the L2: FETCH_SIZE 604 MB for ≈ 100 MB of lines, profiles/r05_notes.md §5).
-    constexpr int CR = 6;
+    constexpr int CR = 6; // (4 / 6 / 8 / 12 rows per comb: 107 / 102 / 99 / 96 µs with the chunks' XCD affinity, 93 / 94 µs for 6 / 12 without)
     const int rd = ry > 0 ? ry : 1;
     const uint32_t combs = uint32_t((H + CR * rd - 1) / (CR * rd)) * uint32_t(rd); // bands of CR·ry rows, ry combs each
-    // A chunk of columns stays on ONE XCD (workgroups go round the XCDs: chunk c ↔ the workgroups ≡ c mod 8): the two chunks of a candidate's
-    // columns and the neighbouring combs share lines of E.
-    const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t xcd_waves = (gridDim.x + 7u - xcd) / 8u * 4u, xcd_wave = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);
-    const uint32_t my_chunks = (chunk_prefix[32] + 7u - xcd) / 8u;
+    // Chunks in plain order over all waves.  (Blocks of adjacent rows wanted a chunk of columns on ONE XCD — 150 → 130 µs then; with the combs every
+    // row of E under a chunk is read once and the affinity costs: 102 against 93 µs.)
     int ci = 0;
 #if defined(LK_SKIP) && (LK_SKIP & 2)
     if(false)
 #endif
-    for(uint32_t u = xcd_wave; u < my_chunks * combs; u += xcd_waves)
+    for(uint32_t u = wave_id; u < chunk_prefix[32] * combs; u += n_waves)
     {
-        const uint32_t chunk = xcd + 8u * (u / combs), comb = u % combs;
+        const uint32_t chunk = u / combs, comb = u % combs;
         prefix_walk(chunk_prefix, chunk, ci);
         const int j = int(chunk - chunk_prefix[ci]) * 64 + lane;
         if(j >= ncols[ci])
