@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256, 2) blend_afs(const KernelArgs a, const in
         asm volatile("" : "+v"(ox_tab[c]), "+v"(oy_tab[c]));
 
     const int G = gridDim.x;
-    const int t0 = int(xcd_contiguous(blockIdx.x, gridDim.x));
+    const int t0 = int(tile_of_block(blockIdx.x, gridDim.x, a.flags));
     if(t0 >= n_tiles)
         return;
     const int T = (n_tiles - 1 - t0) / G + 1; // this workgroup's tiles: t0, t0 + G, …

@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256 / VG, 2) blend_p3(const KernelArgs a, cons
         }
 
     const int G = gridDim.x;
-    const int t0 = int(xcd_contiguous(blockIdx.x, gridDim.x));
+    const int t0 = int(tile_of_block(blockIdx.x, gridDim.x, a.flags));
     if(t0 >= n_tiles)
         return;
     __syncthreads(); // the offset table is complete

@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256, 2) blend_planar(const KernelArgs a, const
     };
 
     const int G = gridDim.x;
-    int t = int(xcd_contiguous(blockIdx.x, gridDim.x));
+    int t = int(tile_of_block(blockIdx.x, gridDim.x, a.flags));
     if(t >= n_tiles)
         return;
     __syncthreads(); // the offset table is complete

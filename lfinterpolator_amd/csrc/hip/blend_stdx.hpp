@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdx(const KernelArgs a, const i
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
     const int G = gridDim.x;
-    const int t0 = int(xcd_contiguous(blockIdx.x, gridDim.x));
+    const int t0 = int(tile_of_block(blockIdx.x, gridDim.x, a.flags));
     if(t0 >= n_tiles)
         return;
     __syncthreads(); // the offset table is complete

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256, 2) blend_stdxa(const KernelArgs a, const 
 
     // ---- unit sequence of this workgroup: tiles j, j + G, …; NU units each; two buffers, one unit ahead --------------------------------------
     const int G = gridDim.x;
-    int t = int(xcd_contiguous(blockIdx.x, gridDim.x));
+    int t = int(tile_of_block(blockIdx.x, gridDim.x, a.flags));
     if(t >= n_tiles)
         return;
     int buf = 0, prev_stores = 0;

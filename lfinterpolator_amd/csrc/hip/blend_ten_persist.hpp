@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256, WGS)
     // them) and per unit otherwise; weight buffers alternate per unit.
     const int G = gridDim.x;
     const bool single_chunk = a.k_pad <= KC;
-    int t = int(xcd_contiguous(blockIdx.x, gridDim.x));
+    int t = int(tile_of_block(blockIdx.x, gridDim.x, a.flags));
     if(t >= n_tiles)
         return;
     int pass = 0, k0 = 0, pbuf = 0, wbuf = 0;

@@ -115,6 +115,18 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t nblocks)
     return xcd * q + min(xcd, rem) + idx;
 }
 
+// Internal bit of KernelArgs::flags (not an LFI_FLAG_*: set by the dispatcher per launch): the launch's tiles share NO cache lines with their
+// neighbours — fixed-focus renders from the planar copy while its per-image phases are tuned for the offsets in use (every 128-byte run IS a
+// line), all-focus renders (per-pixel gathers) — so block b takes tile b: neighbouring tiles run at the same time on DIFFERENT XCDs and their
+// rows' neighbouring lines stream from memory together.  Round 5, second session (profiles/r05_notes.md §8): against the contiguous runs per XCD
+// config 4's ranks −8 %, config 4 whole −3 %, config 5 with RGBA views −8 %, all-focus STD −3 %; with STALE phases (a fixed-focus sweep: runs
+// straddle lines, neighbours share them) the contiguous runs win by 9–14 % — hence a flag and not a rule.
+constexpr uint32_t LFI_KFLAG_PLAIN_TILE_ORDER = 1u << 31;
+__device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t nblocks, uint32_t flags)
+{
+    return (flags & LFI_KFLAG_PLAIN_TILE_ORDER) ? b : xcd_contiguous(b, nblocks);
+}
+
 // Vertical stripes: XCD x owns tile columns [x·tiles_x/8, (x+1)·tiles_x/8) and walks them row by row, `inner` work items per
 // tile back to back.  For kernels whose tiles re-read a band of rows above and below: the band × stripe width × planes is
 // what has to stay in one L2, instead of band × image width.  Launch 8·stripe_blocks_per_xcd(...) blocks; returns false

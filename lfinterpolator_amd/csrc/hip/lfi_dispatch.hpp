@@ -364,6 +364,18 @@ int next_sweep_direction(const lfi_ctx *c)
 #ifndef LFI_PLANAR_ALIGN
 #define LFI_PLANAR_ALIGN 128
 #endif
+// are the planar copy's per-image phases the ones that align the runs of the offsets in use?  (then no tile shares a cache line with its
+// neighbours: LFI_KFLAG_PLAIN_TILE_ORDER, lfi_device.hpp)
+bool planar_phases_tuned(const lfi_ctx *c)
+{
+    if(!c->planar || (int)c->planar_phase.size() != c->n)
+        return false;
+    for(int g = 0; g < c->n; g++)
+        if((c->h_focused[g].x + c->planar_padx + c->planar_phase[g]) & (LFI_PLANAR_ALIGN - 1))
+            return false;
+    return true;
+}
+
 bool ensure_planar(lfi_ctx *c, bool tune = false)
 {
     if(!c->grid_tracked)
@@ -697,6 +709,8 @@ int launch_blend(lfi_ctx *c, int method, int all_focus, const KernelArgs &a_in)
         a.planar_pitch = c->planar_pitch;
         a.planar_padx = c->planar_padx;
         a.planar_phase = c->d_planar_phase; // allocated by ensure_planar, possibly just now
+        if(planar_phases_tuned(c))
+            a.flags |= lfi::LFI_KFLAG_PLAIN_TILE_ORDER;
         launch_p3(c, a);
         LFI_HIP(c, hipGetLastError());
         return LFI_OK;
@@ -740,7 +754,11 @@ int launch_blend_rgba(lfi_ctx *c, int method, int all_focus, const KernelArgs &a
         a.planar_pitch = c->planar_pitch;
         a.planar_padx = c->planar_padx;
         a.planar_phase = c->d_planar_phase; // allocated by ensure_planar, possibly just now
+        if(planar_phases_tuned(c))
+            a.flags |= lfi::LFI_KFLAG_PLAIN_TILE_ORDER;
     }
+    if(all_focus)
+        a.flags |= lfi::LFI_KFLAG_PLAIN_TILE_ORDER; // per-pixel gathers: no lines shared between neighbouring tiles by construction
     if(c->windowed)
     {
         // a row window is honoured by the persistent kernels only

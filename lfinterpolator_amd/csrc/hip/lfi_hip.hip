@@ -660,7 +660,7 @@ int lfi_set_params(lfi_ctx *ctx, const lfi_params *p)
     }
     ctx->radius[0] = std::max(p->block_radius[0], 1);
     ctx->radius[1] = std::max(p->block_radius[1], 1);
-    ctx->flags = p->flags;
+    ctx->flags = p->flags & 0x7fffffffu; // (bit 31 is the dispatcher's own: LFI_KFLAG_PLAIN_TILE_ORDER, lfi_device.hpp)
 
     if(views_changed || !ctx->views)
     {
