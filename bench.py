@@ -300,7 +300,7 @@ def also_table(L, device_index: int, iters: int, layout: str) -> dict:
         out["config5_focus_map"] = {"workload": "15x15 LF @3840x2160, focus map (estimate over 32 views x 32 candidates x 9 taps + filter)",
                                     "kernel": "focus_factored passes + focus_filter", "ms": ms_map,
                                     "algorithmic_bytes": map_in + map_io, "frac": (map_in + map_io) / ms_map / 1e6 / HBM_PEAK_GBS,
-                                    "note": "bound by VALU issue / L2 (DESIGN.md 4.3), not HBM: the fraction is reported for completeness"}
+                                    "note": "the range pass is LDS-bound (DESIGN.md 4.3), not HBM-bound: the fraction is reported for completeness"}
         # the same call when the inputs changed since the last one: the padded copies of the sampled images are rebuilt (otherwise kept
         # between calls — a focus sweep over one light field, which is what BASELINE config 5 is, pads once)
         ms_map_cold = timed(ctx, lambda: (ctx.grid_modified(), ctx.focus_map()), max(2, iters // 4), warm=1)
