@@ -99,7 +99,7 @@ typedef struct lfi_params {
     float focus;                      /* inFocus, src/interpolator.cu:152 */
     float range;                      /* inRange, src/interpolator.cu:153 */
     int32_t block_radius[2];          /* constants[9..10], src/interpolator.cu:142-150 */
-    uint32_t flags;                   /* LFI_FLAG_* */
+    uint32_t flags;                   /* LFI_FLAG_* (bit 31 is reserved for the library and ignored) */
 } lfi_params;
 
 typedef struct lfi_bench_stats {
